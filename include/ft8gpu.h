@@ -1,0 +1,192 @@
+/*
+ * ft8gpu.h -- C ABI of libft8gpu.so: the FT8 decode hot path of Guenael/rtlsdr-ft8d on one
+ * AMD MI355X (gfx950), as hand-written HIP kernels behind the reference's own function boundary.
+ *
+ * Everything here is plain C: pointers, sizes, POD structs.  No HIP, torch or C++ types.
+ * Every entry point names the reference interface it replaces (file:line into the reference).
+ *
+ * Frame conventions (identical to the reference, rtlsdr_ft8d.h:34-56, rtlsdr_ft8d.c:274-278):
+ *   one frame = 15 s at 3200 sps = 48000 complex samples, planar float32: I[48000] then Q[48000].
+ *   A batch is `nframes` such frames back to back: iq[nframes][2][48000].
+ *   waterfall = uint8 mag[92][2][2][256] (block, time_sub, freq_sub, bin) = 94208 bytes per frame.
+ */
+#ifndef FT8GPU_H
+#define FT8GPU_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* the library is built with -fvisibility=hidden; only the C ABI below is exported */
+#pragma GCC visibility push(default)
+
+/* ---- constants: rtlsdr_ft8d.h:34-56 ------------------------------------------------------- */
+#define FT8GPU_NSAMPLES        48000   /* SIGNAL_LENGHT * SIGNAL_SAMPLE_RATE */
+#define FT8GPU_K_MIN_SCORE     10      /* K_MIN_SCORE      rtlsdr_ft8d.h:43 */
+#define FT8GPU_K_MAX_CANDIDATES 120    /* K_MAX_CANDIDATES rtlsdr_ft8d.h:44 */
+#define FT8GPU_K_LDPC_ITERS    20      /* K_LDPC_ITERS     rtlsdr_ft8d.h:45 */
+#define FT8GPU_K_MAX_MESSAGES  50      /* K_MAX_MESSAGES   rtlsdr_ft8d.h:46 */
+#define FT8GPU_NUM_BIN         256     /* NUM_BIN          rtlsdr_ft8d.h:51 */
+#define FT8GPU_NFFT            1024    /* NFFT             rtlsdr_ft8d.h:54 */
+#define FT8GPU_NUM_BLOCKS      92      /* NUM_BLOCKS       rtlsdr_ft8d.h:55 */
+#define FT8GPU_MAG_ARRAY       94208   /* MAG_ARRAY        rtlsdr_ft8d.h:56 */
+#define FT8GPU_NN              79      /* FT8_NN (ft8_lib constants.h; used rtlsdr_ft8d.c:933,:947) */
+#define FT8GPU_ABS_MAX_CANDIDATES 1024 /* upper bound accepted for ft8gpu_params.max_candidates */
+
+/* ---- ABI structs --------------------------------------------------------------------------- */
+
+/* struct decoder_results, rtlsdr_ft8d.h:136-141 (offsets 0/13/20/24, size 28).  The name is kept
+ * so that rtlsdr_ft8d.c compiles against this header unchanged. */
+#ifndef FT8GPU_NO_DECODER_RESULTS
+struct decoder_results {
+    char    call[13];
+    char    loc[7];
+    int32_t freq;
+    int32_t snr;
+};
+#endif
+
+/* candidate_t of ft8_lib decode.h, as used at rtlsdr_ft8d.c:1439, :1466-1470 (8 bytes) */
+typedef struct {
+    int16_t score;
+    int16_t time_offset;
+    int16_t freq_offset;
+    uint8_t time_sub;
+    uint8_t freq_sub;
+} ft8gpu_candidate;
+
+/* Per-candidate outcome of ft8_decode(): message_t + decode_status_t of ft8_lib decode.h
+ * (rtlsdr_ft8d.c:1474-1487, :1494) folded into one 48-byte record, plus the packed 91 bits. */
+typedef struct {
+    int16_t  ldpc_errors;     /* decode_status_t.ldpc_errors (min parity errors seen, 0 = codeword) */
+    int16_t  iters;           /* BP iterations entered before exit (diagnostic) */
+    uint16_t crc_extracted;   /* valid when ldpc_errors == 0 */
+    uint16_t crc_calculated;  /* valid when ldpc_errors == 0 */
+    int8_t   unpack_status;   /* valid when CRCs match; < 0 = unpack77 failed */
+    uint8_t  ok;              /* 1 iff ft8_decode() would have returned true */
+    uint8_t  a91[12];         /* packed payload+CRC bits of the last hard decision */
+    char     text[25];        /* message_t.text (valid when ok) */
+    uint8_t  pad;
+} ft8gpu_decode_status;
+
+/* run-time forms of K_MIN_SCORE / K_MAX_CANDIDATES / K_LDPC_ITERS (rtlsdr_ft8d.h:43-45) */
+typedef struct {
+    int32_t min_score;
+    int32_t max_candidates;
+    int32_t ldpc_iters;
+} ft8gpu_params;
+
+typedef struct ft8gpu_ctx ft8gpu_ctx;
+
+/* flags for the batch entry points */
+#define FT8GPU_HOST_PTRS    0   /* all array arguments are host memory; copies are staged by the library */
+#define FT8GPU_DEVICE_PTRS  1   /* all array arguments are device (HBM) pointers on the context's GPU */
+
+/* per-stage kernel timings of ft8gpu_decode_batch(), hipEvent-measured on the context stream and
+ * averaged over the pipeline runs recorded since ft8gpu_enable_timing(ctx, 1) (ring of 32 runs;
+ * recording does not synchronise the host) */
+typedef struct {
+    float waterfall_ms;
+    float sync_ms;        /* score + compaction */
+    float heap_ms;        /* top-N selection (exact heap replay) */
+    float decode_ms;      /* LLR + LDPC BP + CRC + unpack */
+    float spots_ms;       /* dedup + CQ spot fill */
+    float total_ms;       /* first kernel start to last kernel end */
+} ft8gpu_timings;
+
+/* ---- lifecycle: replaces initFFTW()/freeFFTW(), rtlsdr_ft8d.c:314-347 ----------------------- */
+
+/* Creates a decoder context on GPU `device` with persistent buffers for up to `max_frames` frames.
+ * `params` may be NULL (reference defaults 10 / 120 / 20).  Returns 0 on success. */
+int  ft8gpu_create(ft8gpu_ctx **out, int device, int max_frames, const ft8gpu_params *params);
+void ft8gpu_destroy(ft8gpu_ctx *ctx);
+/* Use an existing hipStream_t (passed as void*) for all work of this context; NULL = own stream. */
+int  ft8gpu_set_stream(ft8gpu_ctx *ctx, void *hip_stream);
+int  ft8gpu_set_params(ft8gpu_ctx *ctx, const ft8gpu_params *params);
+int  ft8gpu_enable_timing(ft8gpu_ctx *ctx, int on);
+int  ft8gpu_get_timings(ft8gpu_ctx *ctx, ft8gpu_timings *out, int32_t *nruns);
+int  ft8gpu_synchronize(ft8gpu_ctx *ctx);
+/* The reference path has no error channel (void ft8_subsystem, rtlsdr_ft8d.h:164); failures are
+ * reported here and by the int return codes of the batch API (0 = ok, <0 = error). */
+const char *ft8gpu_last_error(void);
+int  ft8gpu_device_count(void);
+
+/* ---- the whole path: ft8_subsystem(), rtlsdr_ft8d.c:1387-1524, for `nframes` frames ----------
+ * decodes:   [nframes][50] struct decoder_results.  Exactly as the reference (:1509-1520), slot k
+ *            of a frame is written only if the k-th unique message of that frame starts with "CQ";
+ *            other slots are left untouched.  n_results[f] = number of unique messages (:1523).
+ * Fences (documented deviations where the reference is undefined): more than 50 unique messages
+ * in a frame -> the surplus is dropped (reference: infinite loop); missing tokens -> "(null)". */
+int ft8gpu_decode_batch(ft8gpu_ctx *ctx, const float *iq, int nframes,
+                        struct decoder_results *decodes, int32_t *n_results, int flags);
+
+/* ---- stage entries (same data, stage by stage; used by the parity tests) --------------------- */
+/* rtlsdr_ft8d.c:1395-1435: window, 184 FFTs, log-magnitude, quantise.  mag: [nframes][94208] */
+int ft8gpu_waterfall(ft8gpu_ctx *ctx, const float *iq, int nframes, uint8_t *mag, int flags);
+/* ft8_find_sync(&power, K_MAX_CANDIDATES, candidate_list, K_MIN_SCORE), rtlsdr_ft8d.c:1450.
+ * cands: [nframes][max_candidates], counts: [nframes] */
+int ft8gpu_find_sync(ft8gpu_ctx *ctx, const uint8_t *mag, int nframes,
+                     ft8gpu_candidate *cands, int32_t *counts, int flags);
+/* every sync score of the scan, int16 [nframes][2][2][36][249] (diagnostic / parity) */
+int ft8gpu_score_map(ft8gpu_ctx *ctx, const uint8_t *mag, int nframes, int16_t *scores, int flags);
+/* ft8_decode(&power, cand, &message, K_LDPC_ITERS, &status) for every candidate, :1476.
+ * status: [nframes][max_candidates] */
+int ft8gpu_decode_candidates(ft8gpu_ctx *ctx, const uint8_t *mag, const ft8gpu_candidate *cands,
+                             const int32_t *counts, int nframes, ft8gpu_decode_status *status, int flags);
+/* dedup hash table + CQ filter + spot fill, rtlsdr_ft8d.c:1452-1460, :1487-1523 */
+int ft8gpu_collect_spots(ft8gpu_ctx *ctx, const ft8gpu_candidate *cands, const int32_t *counts,
+                         const ft8gpu_decode_status *status, int nframes,
+                         struct decoder_results *decodes, int32_t *n_results, int flags);
+
+/* ---- tooling: encoder + synthetic frames (pack77 / ft8_encode / CPFSK synth of
+ *      decoderSelfTest, rtlsdr_ft8d.c:924-955) --------------------------------------------- */
+/* "CALL1 CALL2 GRID4" standard (type 1) message -> 77 bits in 10 bytes (pack77, :927). 0 = ok */
+int  ft8gpu_pack77_std(const char *msg, uint8_t payload[10]);
+/* payload -> 79 tone numbers (ft8_encode, :934) */
+void ft8gpu_encode(const uint8_t payload[10], uint8_t tones[FT8GPU_NN]);
+
+typedef struct {
+    uint8_t tones[FT8GPU_NN];
+    uint8_t pad;
+    float   f0_hz;        /* frequency of tone 0 */
+    float   t0_s;         /* start time within the frame */
+    float   amplitude;    /* linear amplitude (noise has unit power in 3200 Hz before normalisation) */
+} ft8gpu_synth_signal;
+
+/* Synthesises frames directly in HBM: complex AWGN (variance noise_sigma^2 per component) plus
+ * nsig_per_frame CPFSK signals per frame (plain FSK as rtlsdr_ft8d.c:946-955), then peak-normalises
+ * each frame to 0.5 as the decoder thread does (rtlsdr_ft8d.c:248-263).
+ * signals: host array [nframes][nsig_per_frame]; iq_dev: device pointer [nframes][2][48000]. */
+int ft8gpu_synth_frames(ft8gpu_ctx *ctx, const ft8gpu_synth_signal *signals, int nframes,
+                        int nsig_per_frame, float noise_sigma, uint64_t seed, float *iq_dev);
+
+/* device memory helpers so that a plain C caller needs no HIP headers */
+void *ft8gpu_dev_alloc(size_t bytes);
+void  ft8gpu_dev_free(void *p);
+int   ft8gpu_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int   ft8gpu_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---- drop-in symbols of the reference (rtlsdr_ft8d.h:155-156, :164) --------------------------
+ * Link rtlsdr_ft8d.c against libft8gpu.so instead of its own ft8_subsystem/initFFTW/freeFFTW
+ * (INTEGRATION.md).  They drive a process-global single-frame context on GPU 0
+ * (env FT8GPU_DEVICE overrides). */
+void initFFTW(void);
+void freeFFTW(void);
+void ft8_subsystem(float *iSamples, float *qSamples, uint32_t samples_len,
+                   struct decoder_results *decodes, int32_t *n_results);
+
+/* .iq / .c2 readers and writer with the reference's conventions (rtlsdr_ft8d.c:744-856):
+ * interleaved float32 I,Q on disk, Q negated, peak-normalised to 0.5 on load. */
+int32_t ft8gpu_read_raw_iq(float *iSamples, float *qSamples, const char *filename);
+int32_t ft8gpu_read_c2(float *iSamples, float *qSamples, const char *filename, double *dialfreq);
+int32_t ft8gpu_write_raw_iq(const float *iSamples, const float *qSamples, const char *filename);
+
+#pragma GCC visibility pop
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FT8GPU_H */

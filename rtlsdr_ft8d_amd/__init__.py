@@ -1,0 +1,280 @@
+"""rtlsdr_ft8d_amd -- Python view of libft8gpu.so (include/ft8gpu.h).
+
+The product is the C-ABI shared library built from ``csrc/`` (hand-written HIP kernels for
+gfx950 + C host side).  This module only binds it with ctypes for the tests and ``bench.py``;
+there is no Python or CPU fallback: if the library is missing, import of the binding raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libft8gpu.so")
+
+NSAMPLES = 48000            # rtlsdr_ft8d.h:34-35
+MAG_ARRAY = 94208           # rtlsdr_ft8d.h:56
+MAX_MESSAGES = 50           # rtlsdr_ft8d.h:46
+SCORES_PER_FRAME = 2 * 2 * 36 * 249
+HOST_PTRS, DEVICE_PTRS = 0, 1
+
+RESULT_DTYPE = np.dtype([("call", "S13"), ("loc", "S7"), ("freq", "<i4"), ("snr", "<i4")], align=True)
+CAND_DTYPE = np.dtype([("score", "<i2"), ("time_offset", "<i2"), ("freq_offset", "<i2"),
+                       ("time_sub", "u1"), ("freq_sub", "u1")])
+STATUS_DTYPE = np.dtype([("ldpc_errors", "<i2"), ("iters", "<i2"), ("crc_extracted", "<u2"),
+                         ("crc_calculated", "<u2"), ("unpack_status", "i1"), ("ok", "u1"),
+                         ("a91", "u1", (12,)), ("text", "S25"), ("pad", "u1")])
+SIGNAL_DTYPE = np.dtype([("tones", "u1", (79,)), ("pad", "u1"), ("f0_hz", "<f4"), ("t0_s", "<f4"),
+                         ("amplitude", "<f4")])
+assert RESULT_DTYPE.itemsize == 28 and CAND_DTYPE.itemsize == 8
+assert STATUS_DTYPE.itemsize == 48 and SIGNAL_DTYPE.itemsize == 92
+
+
+class Params(C.Structure):
+    _fields_ = [("min_score", C.c_int32), ("max_candidates", C.c_int32), ("ldpc_iters", C.c_int32)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("waterfall_ms", C.c_float), ("sync_ms", C.c_float), ("heap_ms", C.c_float),
+                ("decode_ms", C.c_float), ("spots_ms", C.c_float), ("total_ms", C.c_float)]
+
+
+class Ft8GpuError(RuntimeError):
+    pass
+
+
+ABI_SYMBOLS = [
+    "ft8gpu_create", "ft8gpu_destroy", "ft8gpu_set_stream", "ft8gpu_set_params", "ft8gpu_enable_timing",
+    "ft8gpu_get_timings", "ft8gpu_synchronize", "ft8gpu_last_error", "ft8gpu_device_count",
+    "ft8gpu_decode_batch", "ft8gpu_waterfall", "ft8gpu_find_sync", "ft8gpu_score_map",
+    "ft8gpu_decode_candidates", "ft8gpu_collect_spots", "ft8gpu_pack77_std", "ft8gpu_encode",
+    "ft8gpu_synth_frames", "ft8gpu_dev_alloc", "ft8gpu_dev_free", "ft8gpu_memcpy_h2d", "ft8gpu_memcpy_d2h",
+    "initFFTW", "freeFFTW", "ft8_subsystem", "ft8gpu_read_raw_iq", "ft8gpu_read_c2", "ft8gpu_write_raw_iq",
+]
+
+_lib = None
+
+
+def load_library():
+    """dlopen libft8gpu.so and declare prototypes.  Raises if the HIP extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # PyTorch wheels bundle their own HIP/HSA runtime under the same SONAME (libamdhip64.so.7) as
+    # /opt/rocm's.  A process must hold exactly ONE of them: two copies each open the GPU and the
+    # second one finds no devices.  Importing torch first makes the dynamic loader resolve this
+    # library's libamdhip64.so.7 dependency to the copy torch already mapped.  (A plain C caller
+    # such as rtlsdr_ft8d.c simply gets /opt/rocm's runtime.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    if not os.path.exists(LIB_PATH):
+        raise Ft8GpuError(
+            f"{LIB_PATH} is missing: build it with `make -C rtlsdr_ft8d_amd/csrc` "
+            "(or __graft_entry__.build()).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32p = C.c_void_p, C.POINTER(C.c_int32)
+    L.ft8gpu_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(Params)]
+    L.ft8gpu_destroy.argtypes = [vp]
+    L.ft8gpu_destroy.restype = None
+    L.ft8gpu_set_stream.argtypes = [vp, vp]
+    L.ft8gpu_set_params.argtypes = [vp, C.POINTER(Params)]
+    L.ft8gpu_enable_timing.argtypes = [vp, C.c_int]
+    L.ft8gpu_get_timings.argtypes = [vp, C.POINTER(Timings), C.POINTER(C.c_int32)]
+    L.ft8gpu_synchronize.argtypes = [vp]
+    L.ft8gpu_last_error.restype = C.c_char_p
+    L.ft8gpu_decode_batch.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int]
+    L.ft8gpu_waterfall.argtypes = [vp, vp, C.c_int, vp, C.c_int]
+    L.ft8gpu_find_sync.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int]
+    L.ft8gpu_score_map.argtypes = [vp, vp, C.c_int, vp, C.c_int]
+    L.ft8gpu_decode_candidates.argtypes = [vp, vp, vp, vp, C.c_int, vp, C.c_int]
+    L.ft8gpu_collect_spots.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int]
+    L.ft8gpu_pack77_std.argtypes = [C.c_char_p, vp]
+    L.ft8gpu_encode.argtypes = [vp, vp]
+    L.ft8gpu_encode.restype = None
+    L.ft8gpu_synth_frames.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, C.c_uint64, vp]
+    L.ft8gpu_dev_alloc.argtypes = [C.c_size_t]
+    L.ft8gpu_dev_alloc.restype = vp
+    L.ft8gpu_dev_free.argtypes = [vp]
+    L.ft8gpu_dev_free.restype = None
+    L.ft8gpu_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
+    L.ft8gpu_memcpy_d2h.argtypes = [vp, vp, C.c_size_t]
+    L.initFFTW.restype = None
+    L.freeFFTW.restype = None
+    L.ft8_subsystem.argtypes = [vp, vp, C.c_uint32, vp, i32p]
+    L.ft8_subsystem.restype = None
+    L.ft8gpu_read_raw_iq.argtypes = [vp, vp, C.c_char_p]
+    L.ft8gpu_read_raw_iq.restype = C.c_int32
+    L.ft8gpu_read_c2.argtypes = [vp, vp, C.c_char_p, C.POINTER(C.c_double)]
+    L.ft8gpu_read_c2.restype = C.c_int32
+    L.ft8gpu_write_raw_iq.argtypes = [vp, vp, C.c_char_p]
+    L.ft8gpu_write_raw_iq.restype = C.c_int32
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise Ft8GpuError(load_library().ft8gpu_last_error().decode(errors="replace"))
+
+
+def _ptr(a):
+    """host numpy array or device pointer (int / torch tensor) -> integer address"""
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):
+        return a.data_ptr()
+    return int(a)
+
+
+def pack77_std(msg):
+    out = np.zeros(10, np.uint8)
+    rc = load_library().ft8gpu_pack77_std(msg.encode(), out.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"cannot pack {msg!r} as a standard FT8 message")
+    return out
+
+
+def encode(payload):
+    payload = np.ascontiguousarray(payload, np.uint8)
+    tones = np.zeros(79, np.uint8)
+    load_library().ft8gpu_encode(payload.ctypes.data, tones.ctypes.data)
+    return tones
+
+
+class Decoder:
+    """One GPU decoder context (ft8gpu_ctx).  Host arrays are numpy; device arrays are anything
+    with ``data_ptr()`` (torch tensors) or raw integer addresses."""
+
+    def __init__(self, device=0, max_frames=64, min_score=10, max_candidates=120, ldpc_iters=20):
+        self.lib = load_library()
+        self.params = Params(min_score, max_candidates, ldpc_iters)
+        self.max_frames = max_frames
+        h = C.c_void_p()
+        _check(self.lib.ft8gpu_create(C.byref(h), device, max_frames, C.byref(self.params)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ft8gpu_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def max_candidates(self):
+        return self.params.max_candidates
+
+    def set_params(self, min_score=None, max_candidates=None, ldpc_iters=None):
+        p = Params(self.params.min_score if min_score is None else min_score,
+                   self.params.max_candidates if max_candidates is None else max_candidates,
+                   self.params.ldpc_iters if ldpc_iters is None else ldpc_iters)
+        _check(self.lib.ft8gpu_set_params(self.h, C.byref(p)))
+        self.params = p
+
+    def set_stream(self, stream_handle):
+        _check(self.lib.ft8gpu_set_stream(self.h, C.c_void_p(stream_handle or None)))
+
+    def enable_timing(self, on=True):
+        _check(self.lib.ft8gpu_enable_timing(self.h, int(on)))
+
+    def timings(self):
+        """mean per-stage milliseconds over the runs recorded since enable_timing(True)"""
+        t, n = Timings(), C.c_int32(0)
+        _check(self.lib.ft8gpu_get_timings(self.h, C.byref(t), C.byref(n)))
+        d = {k: getattr(t, k) for k, _ in Timings._fields_}
+        d["runs"] = n.value
+        return d
+
+    def synchronize(self):
+        _check(self.lib.ft8gpu_synchronize(self.h))
+
+    # ---- host (numpy) API ------------------------------------------------------------------
+    def decode_batch(self, iq, decodes=None):
+        iq = np.ascontiguousarray(iq, np.float32)
+        B = iq.shape[0]
+        assert iq.shape[1:] == (2, NSAMPLES)
+        if decodes is None:
+            decodes = np.zeros((B, MAX_MESSAGES), RESULT_DTYPE)
+        n = np.zeros(B, np.int32)
+        _check(self.lib.ft8gpu_decode_batch(self.h, iq.ctypes.data, B, decodes.ctypes.data, n.ctypes.data, HOST_PTRS))
+        return decodes, n
+
+    def waterfall(self, iq):
+        iq = np.ascontiguousarray(iq, np.float32)
+        B = iq.shape[0]
+        assert iq.shape[1:] == (2, NSAMPLES)
+        mag = np.zeros((B, MAG_ARRAY), np.uint8)
+        _check(self.lib.ft8gpu_waterfall(self.h, iq.ctypes.data, B, mag.ctypes.data, HOST_PTRS))
+        return mag
+
+    def find_sync(self, mag):
+        mag = np.ascontiguousarray(mag, np.uint8).reshape(-1, MAG_ARRAY)
+        B = mag.shape[0]
+        cands = np.zeros((B, self.max_candidates), CAND_DTYPE)
+        counts = np.zeros(B, np.int32)
+        _check(self.lib.ft8gpu_find_sync(self.h, mag.ctypes.data, B, cands.ctypes.data, counts.ctypes.data, HOST_PTRS))
+        return cands, counts
+
+    def score_map(self, mag):
+        mag = np.ascontiguousarray(mag, np.uint8).reshape(-1, MAG_ARRAY)
+        B = mag.shape[0]
+        s = np.zeros((B, 2, 2, 36, 249), np.int16)
+        _check(self.lib.ft8gpu_score_map(self.h, mag.ctypes.data, B, s.ctypes.data, HOST_PTRS))
+        return s
+
+    def decode_candidates(self, mag, cands, counts):
+        mag = np.ascontiguousarray(mag, np.uint8).reshape(-1, MAG_ARRAY)
+        B = mag.shape[0]
+        cands = np.ascontiguousarray(cands)
+        counts = np.ascontiguousarray(counts, np.int32)
+        assert cands.shape == (B, self.max_candidates) and cands.dtype == CAND_DTYPE
+        st = np.zeros((B, self.max_candidates), STATUS_DTYPE)
+        _check(self.lib.ft8gpu_decode_candidates(self.h, mag.ctypes.data, cands.ctypes.data, counts.ctypes.data,
+                                                 B, st.ctypes.data, HOST_PTRS))
+        return st
+
+    def collect_spots(self, cands, counts, status, decodes=None):
+        cands = np.ascontiguousarray(cands)
+        counts = np.ascontiguousarray(counts, np.int32)
+        status = np.ascontiguousarray(status)
+        B = counts.shape[0]
+        if decodes is None:
+            decodes = np.zeros((B, MAX_MESSAGES), RESULT_DTYPE)
+        n = np.zeros(B, np.int32)
+        _check(self.lib.ft8gpu_collect_spots(self.h, cands.ctypes.data, counts.ctypes.data, status.ctypes.data, B,
+                                             decodes.ctypes.data, n.ctypes.data, HOST_PTRS))
+        return decodes, n
+
+    # ---- device-pointer API (inputs and outputs resident in HBM) --------------------------------
+    def decode_batch_dev(self, iq_dev, nframes, decodes_dev, n_results_dev):
+        _check(self.lib.ft8gpu_decode_batch(self.h, _ptr(iq_dev), nframes, _ptr(decodes_dev), _ptr(n_results_dev),
+                                            DEVICE_PTRS))
+
+    def waterfall_dev(self, iq_dev, nframes, mag_dev):
+        _check(self.lib.ft8gpu_waterfall(self.h, _ptr(iq_dev), nframes, _ptr(mag_dev), DEVICE_PTRS))
+
+    def synth_frames(self, signals, nframes, nsig, noise_sigma, seed, iq_dev):
+        signals = np.ascontiguousarray(signals)
+        assert signals.dtype == SIGNAL_DTYPE and signals.size == nframes * nsig
+        _check(self.lib.ft8gpu_synth_frames(self.h, signals.ctypes.data, nframes, nsig, float(noise_sigma),
+                                            int(seed), _ptr(iq_dev)))
+
+
+def ft8_subsystem(i_samples, q_samples, decodes=None):
+    """The reference's own entry point (rtlsdr_ft8d.h:164) through the drop-in symbol."""
+    L = load_library()
+    i_samples = np.ascontiguousarray(i_samples, np.float32)
+    q_samples = np.ascontiguousarray(q_samples, np.float32)
+    if decodes is None:
+        decodes = np.zeros(MAX_MESSAGES, RESULT_DTYPE)
+    n = C.c_int32(0)
+    L.ft8_subsystem(i_samples.ctypes.data, q_samples.ctypes.data, NSAMPLES, decodes.ctypes.data, C.byref(n))
+    return decodes, n.value

@@ -1,0 +1,458 @@
+// ft8gpu_api.hip -- context, persistent HBM buffers and the C ABI of include/ft8gpu.h.
+// Replaces the process-global FFTW state of the reference (initFFTW/freeFFTW, rtlsdr_ft8d.c:314-347)
+// by an explicit, re-entrant context; the reference-named drop-in symbols live in ft8_compat.c.
+#include "ft8gpu_internal.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return -1;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// The reference's quantiser, rtlsdr_ft8d.c:1416 + :1425-1427, as a function of
+// y = 1e-12f + mag2*4/(NFFT*NFFT), evaluated with the host's libm exactly as the reference does.
+int ref_quant(float y) {
+    const float db = 10.0f * log10f(y);
+    const int scaled = (int)(2 * db + 240);
+    return (scaled < 0) ? 0 : ((scaled > 255) ? 255 : scaled);
+}
+
+uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+// qthr[k] (k = 1..255) = smallest positive float y with ref_quant(y) >= k.  The device quantiser
+// counts thresholds <= y, which reproduces ref_quant bit for bit as long as the host log10f is
+// monotone across each threshold (checked below and by sampling).
+int build_tables(Ft8Tables *t) {
+    for (int i = 0; i < kNfft; i++) t->hann[i] = sinf((M_PI / kNfft) * i);          // rtlsdr_ft8d.c:333
+    for (int k = 0; k < kNfft; k++) {
+        const double a = 2.0 * M_PI * (double)k / (double)kNfft;
+        t->tw[k].x = (float)cos(a);
+        t->tw[k].y = (float)(-sin(a));
+    }
+    memset(t->qthr, 0, sizeof t->qthr);
+    const uint32_t lo_bits = f2u(1E-12f), hi_bits = f2u(FLT_MAX);
+    t->qthr[0] = 0.0f;
+    for (int k = 1; k <= 255; k++) {
+        if (ref_quant(u2f(hi_bits)) < k) { t->qthr[k] = INFINITY; continue; }
+        if (ref_quant(u2f(lo_bits)) >= k) { t->qthr[k] = u2f(lo_bits); continue; }
+        uint32_t lo = lo_bits, hi = hi_bits;              // invariant: q(lo) < k <= q(hi)
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (ref_quant(u2f(mid)) >= k) hi = mid; else lo = mid;
+        }
+        t->qthr[k] = u2f(hi);
+        // local monotonicity: a window of neighbouring floats must sit on the right side
+        for (uint32_t d = 1; d <= 64; d++) {
+            if (ref_quant(u2f(hi + d)) < k || ref_quant(u2f(hi - d)) >= k)
+                return fail("host log10f is not monotone around quantiser threshold %d", k);
+        }
+    }
+    for (int k = 256; k < 260; k++) t->qthr[k] = INFINITY;
+    // sampled global check of the threshold form against the direct expression
+    uint64_t s = 0x243F6A8885A308D3ull;
+    for (int it = 0; it < 200000; it++) {
+        s = s * 6364136223846793005ull + 1442695040888963407ull;
+        const float expo = -12.0f + 18.5f * (float)((s >> 11) & 0xFFFFFF) / 16777216.0f;
+        const float y = 1E-12f + powf(10.0f, expo);
+        int q = 0;
+        for (int k = 1; k <= 255; k++) q += (y >= t->qthr[k]);
+        if (q != ref_quant(y)) return fail("quantiser threshold table disagrees with log10f at y=%g", (double)y);
+    }
+    return 0;
+}
+
+}  // namespace
+
+struct ft8gpu_ctx {
+    int device = 0;
+    int num_cus = 256;
+    int max_frames = 0;
+    int cap_candidates = 0;
+    ft8gpu_params params{ FT8GPU_K_MIN_SCORE, FT8GPU_K_MAX_CANDIDATES, FT8GPU_K_LDPC_ITERS };
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool timing = false;
+    static constexpr int kTimingSlots = 32;
+    hipEvent_t ev[kTimingSlots][6]{};      // ring of per-run stage events (no host sync while timing)
+    long runs = 0;                         // pipeline runs recorded since timing was enabled
+
+    Ft8Tables *d_tab = nullptr;
+    float *d_iq = nullptr;                 // staging for host-pointer calls
+    uint8_t *d_mag = nullptr;
+    uint32_t *d_lists = nullptr;
+    int32_t *d_list_counts = nullptr;
+    ft8gpu_candidate *d_cands = nullptr;
+    int32_t *d_counts = nullptr;
+    ft8gpu_decode_status *d_status = nullptr;
+    struct decoder_results *d_decodes = nullptr;
+    int32_t *d_nres = nullptr;
+    int16_t *d_scores = nullptr;           // lazily allocated (diagnostic)
+    ft8gpu_synth_signal *d_sigs = nullptr;
+    size_t sigs_cap = 0;
+};
+
+namespace {
+
+int alloc_candidate_buffers(ft8gpu_ctx *c, int cap) {
+    if (c->d_cands) { (void)hipFree(c->d_cands); c->d_cands = nullptr; }
+    if (c->d_status) { (void)hipFree(c->d_status); c->d_status = nullptr; }
+    HIP_TRY(hipMalloc(&c->d_cands, (size_t)c->max_frames * cap * sizeof(ft8gpu_candidate)));
+    HIP_TRY(hipMalloc(&c->d_status, (size_t)c->max_frames * cap * sizeof(ft8gpu_decode_status)));
+    c->cap_candidates = cap;
+    return 0;
+}
+
+int check_params(const ft8gpu_params *p) {
+    if (p->max_candidates < 1 || p->max_candidates > FT8GPU_ABS_MAX_CANDIDATES)
+        return fail("max_candidates %d out of range [1, %d]", p->max_candidates, FT8GPU_ABS_MAX_CANDIDATES);
+    if (p->ldpc_iters < 1 || p->ldpc_iters > 1000) return fail("ldpc_iters %d out of range", p->ldpc_iters);
+    if (p->min_score < -32768 || p->min_score > 32767) return fail("min_score %d out of range", p->min_score);
+    return 0;
+}
+
+struct StageTimer {
+    ft8gpu_ctx *c;
+    explicit StageTimer(ft8gpu_ctx *ctx) : c(ctx) {}
+    void mark(int i) { if (c->timing) (void)hipEventRecord(c->ev[c->runs % ft8gpu_ctx::kTimingSlots][i], c->stream); }
+};
+
+float elapsed(hipEvent_t a, hipEvent_t b) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0.f;
+    return ms;
+}
+
+// the pipeline on device pointers; all intermediates in the context's HBM buffers
+int run_pipeline(ft8gpu_ctx *c, const float *d_iq, int n, struct decoder_results *d_dec, int32_t *d_nres) {
+    StageTimer t(c);
+    const ft8gpu_params &p = c->params;
+    t.mark(0);
+    HIP_TRY(launch_waterfall(d_iq, c->d_mag, c->d_tab, n, c->num_cus, c->stream));
+    t.mark(1);
+    HIP_TRY(launch_sync(c->d_mag, c->d_lists, c->d_list_counts, nullptr, n, p.min_score, c->stream));
+    t.mark(2);
+    HIP_TRY(launch_heap(c->d_lists, c->d_list_counts, c->d_cands, c->d_counts, n, p.max_candidates, c->stream));
+    t.mark(3);
+    HIP_TRY(launch_decode(c->d_mag, c->d_cands, c->d_counts, c->d_status, n, p.max_candidates, p.ldpc_iters, c->stream));
+    t.mark(4);
+    HIP_TRY(launch_spots(c->d_cands, c->d_counts, c->d_status, n, p.max_candidates, p.min_score, d_dec, d_nres, c->stream));
+    t.mark(5);
+    if (c->timing) c->runs++;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *ft8gpu_last_error(void) { return g_err; }
+
+int ft8gpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ft8gpu_create(ft8gpu_ctx **out, int device, int max_frames, const ft8gpu_params *params) {
+    if (!out) return fail("ft8gpu_create: out is NULL");
+    *out = nullptr;
+    if (max_frames < 1) return fail("ft8gpu_create: max_frames must be >= 1");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail("ft8gpu_create: device %d not present (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    ft8gpu_ctx *c = new ft8gpu_ctx();
+    c->device = device;
+    c->max_frames = max_frames;
+    if (params) { if (check_params(params)) { delete c; return -1; } c->params = *params; }
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+    for (auto &slot : c->ev) for (auto &e : slot) HIP_TRY(hipEventCreate(&e));
+
+    Ft8Tables *h = (Ft8Tables *)malloc(sizeof(Ft8Tables));
+    if (build_tables(h)) { free(h); ft8gpu_destroy(c); return -1; }
+    HIP_TRY(hipMalloc(&c->d_tab, sizeof(Ft8Tables)));
+    HIP_TRY(hipMemcpy(c->d_tab, h, sizeof(Ft8Tables), hipMemcpyHostToDevice));
+    free(h);
+    HIP_TRY(decode_tables_init(c->stream));
+
+    const size_t F = (size_t)max_frames;
+    HIP_TRY(hipMalloc(&c->d_mag, F * kMagArray));
+    HIP_TRY(hipMalloc(&c->d_lists, F * kSublistsPerFrame * kSublistCap * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&c->d_list_counts, F * kSublistsPerFrame * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&c->d_counts, F * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&c->d_decodes, F * kMaxMessages * sizeof(struct decoder_results)));
+    HIP_TRY(hipMalloc(&c->d_nres, F * sizeof(int32_t)));
+    if (alloc_candidate_buffers(c, c->params.max_candidates < 120 ? 120 : c->params.max_candidates)) { ft8gpu_destroy(c); return -1; }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *out = c;
+    return 0;
+}
+
+void ft8gpu_destroy(ft8gpu_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *bufs[] = { c->d_tab, c->d_iq, c->d_mag, c->d_lists, c->d_list_counts, c->d_cands, c->d_counts,
+                     c->d_status, c->d_decodes, c->d_nres, c->d_scores, c->d_sigs };
+    for (void *b : bufs) if (b) (void)hipFree(b);
+    for (auto &slot : c->ev) for (auto &e : slot) if (e) (void)hipEventDestroy(e);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int ft8gpu_set_stream(ft8gpu_ctx *c, void *hip_stream) {
+    if (!c) return fail("ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->own_stream) { (void)hipStreamDestroy(c->stream); c->own_stream = false; }
+    if (hip_stream) c->stream = (hipStream_t)hip_stream;
+    else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    return 0;
+}
+
+int ft8gpu_set_params(ft8gpu_ctx *c, const ft8gpu_params *p) {
+    if (!c || !p) return fail("NULL argument");
+    if (check_params(p)) return -1;
+    HIP_TRY(hipSetDevice(c->device));
+    if (p->max_candidates > c->cap_candidates) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (alloc_candidate_buffers(c, p->max_candidates)) return -1;
+    }
+    c->params = *p;
+    return 0;
+}
+
+int ft8gpu_enable_timing(ft8gpu_ctx *c, int on) {
+    if (!c) return fail("ctx is NULL");
+    c->timing = on != 0;
+    c->runs = 0;
+    return 0;
+}
+
+// mean over the (up to 32 most recent) pipeline runs recorded since ft8gpu_enable_timing(ctx, 1)
+int ft8gpu_get_timings(ft8gpu_ctx *c, ft8gpu_timings *out, int32_t *nruns) {
+    if (!c || !out) return fail("NULL argument");
+    if (!c->timing || c->runs == 0) return fail("no timed pipeline run recorded");
+    HIP_TRY(hipSetDevice(c->device));
+    const int n = c->runs < ft8gpu_ctx::kTimingSlots ? (int)c->runs : ft8gpu_ctx::kTimingSlots;
+    double acc[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int k = 0; k < n; k++) {
+        hipEvent_t *e = c->ev[(c->runs - 1 - k) % ft8gpu_ctx::kTimingSlots];
+        HIP_TRY(hipEventSynchronize(e[5]));
+        for (int i = 0; i < 5; i++) acc[i] += elapsed(e[i], e[i + 1]);
+        acc[5] += elapsed(e[0], e[5]);
+    }
+    out->waterfall_ms = (float)(acc[0] / n);
+    out->sync_ms = (float)(acc[1] / n);
+    out->heap_ms = (float)(acc[2] / n);
+    out->decode_ms = (float)(acc[3] / n);
+    out->spots_ms = (float)(acc[4] / n);
+    out->total_ms = (float)(acc[5] / n);
+    if (nruns) *nruns = n;
+    return 0;
+}
+
+int ft8gpu_synchronize(ft8gpu_ctx *c) {
+    if (!c) return fail("ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+void *ft8gpu_dev_alloc(size_t bytes) { void *p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) { fail("hipMalloc(%zu) failed", bytes); return nullptr; } return p; }
+void ft8gpu_dev_free(void *p) { if (p) (void)hipFree(p); }
+int ft8gpu_memcpy_h2d(void *d, const void *s, size_t n) { HIP_TRY(hipMemcpy(d, s, n, hipMemcpyHostToDevice)); return 0; }
+int ft8gpu_memcpy_d2h(void *d, const void *s, size_t n) { HIP_TRY(hipMemcpy(d, s, n, hipMemcpyDeviceToHost)); return 0; }
+
+#define CHECK_COMMON(c, n)                                                              \
+    if (!(c)) return fail("ctx is NULL");                                               \
+    if ((n) < 0) return fail("nframes < 0");                                            \
+    HIP_TRY(hipSetDevice((c)->device));
+
+int ft8gpu_decode_batch(ft8gpu_ctx *c, const float *iq, int nframes, struct decoder_results *decodes,
+                        int32_t *n_results, int flags) {
+    CHECK_COMMON(c, nframes);
+    if (nframes == 0) return 0;
+    if (!iq || !decodes || !n_results) return fail("NULL array argument");
+    const size_t frame_floats = 2 * (size_t)kNSamples;
+    for (int f0 = 0; f0 < nframes; f0 += c->max_frames) {
+        const int n = (nframes - f0 < c->max_frames) ? nframes - f0 : c->max_frames;
+        if (flags & FT8GPU_DEVICE_PTRS) {
+            if (run_pipeline(c, iq + f0 * frame_floats, n, decodes + (size_t)f0 * kMaxMessages, n_results + f0)) return -1;
+        } else {
+            if (!c->d_iq) HIP_TRY(hipMalloc(&c->d_iq, (size_t)c->max_frames * frame_floats * sizeof(float)));
+            HIP_TRY(hipMemcpyAsync(c->d_iq, iq + f0 * frame_floats, n * frame_floats * sizeof(float), hipMemcpyHostToDevice, c->stream));
+            // slots of non-CQ messages must keep the caller's bytes (rtlsdr_ft8d.c:1509-1520)
+            HIP_TRY(hipMemcpyAsync(c->d_decodes, decodes + (size_t)f0 * kMaxMessages,
+                                   (size_t)n * kMaxMessages * sizeof(struct decoder_results), hipMemcpyHostToDevice, c->stream));
+            if (run_pipeline(c, c->d_iq, n, c->d_decodes, c->d_nres)) return -1;
+            HIP_TRY(hipMemcpyAsync(decodes + (size_t)f0 * kMaxMessages, c->d_decodes,
+                                   (size_t)n * kMaxMessages * sizeof(struct decoder_results), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(n_results + f0, c->d_nres, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+    }
+    return 0;
+}
+
+int ft8gpu_waterfall(ft8gpu_ctx *c, const float *iq, int nframes, uint8_t *mag, int flags) {
+    CHECK_COMMON(c, nframes);
+    if (nframes == 0) return 0;
+    if (!iq || !mag) return fail("NULL array argument");
+    const size_t frame_floats = 2 * (size_t)kNSamples;
+    for (int f0 = 0; f0 < nframes; f0 += c->max_frames) {
+        const int n = (nframes - f0 < c->max_frames) ? nframes - f0 : c->max_frames;
+        if (flags & FT8GPU_DEVICE_PTRS) {
+            HIP_TRY(launch_waterfall(iq + f0 * frame_floats, mag + (size_t)f0 * kMagArray, c->d_tab, n, c->num_cus, c->stream));
+        } else {
+            if (!c->d_iq) HIP_TRY(hipMalloc(&c->d_iq, (size_t)c->max_frames * frame_floats * sizeof(float)));
+            HIP_TRY(hipMemcpyAsync(c->d_iq, iq + f0 * frame_floats, n * frame_floats * sizeof(float), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(launch_waterfall(c->d_iq, c->d_mag, c->d_tab, n, c->num_cus, c->stream));
+            HIP_TRY(hipMemcpyAsync(mag + (size_t)f0 * kMagArray, c->d_mag, (size_t)n * kMagArray, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+    }
+    return 0;
+}
+
+int ft8gpu_find_sync(ft8gpu_ctx *c, const uint8_t *mag, int nframes, ft8gpu_candidate *cands, int32_t *counts, int flags) {
+    CHECK_COMMON(c, nframes);
+    if (nframes == 0) return 0;
+    if (!mag || !cands || !counts) return fail("NULL array argument");
+    const int mc = c->params.max_candidates;
+    for (int f0 = 0; f0 < nframes; f0 += c->max_frames) {
+        const int n = (nframes - f0 < c->max_frames) ? nframes - f0 : c->max_frames;
+        const bool dev = flags & FT8GPU_DEVICE_PTRS;
+        const uint8_t *dm = dev ? mag + (size_t)f0 * kMagArray : c->d_mag;
+        ft8gpu_candidate *dc = dev ? cands + (size_t)f0 * mc : c->d_cands;
+        int32_t *dn = dev ? counts + f0 : c->d_counts;
+        if (!dev) HIP_TRY(hipMemcpyAsync(c->d_mag, mag + (size_t)f0 * kMagArray, (size_t)n * kMagArray, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(launch_sync(dm, c->d_lists, c->d_list_counts, nullptr, n, c->params.min_score, c->stream));
+        HIP_TRY(launch_heap(c->d_lists, c->d_list_counts, dc, dn, n, mc, c->stream));
+        if (!dev) {
+            HIP_TRY(hipMemcpyAsync(cands + (size_t)f0 * mc, dc, (size_t)n * mc * sizeof(ft8gpu_candidate), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(counts + f0, dn, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+    }
+    return 0;
+}
+
+int ft8gpu_score_map(ft8gpu_ctx *c, const uint8_t *mag, int nframes, int16_t *scores, int flags) {
+    CHECK_COMMON(c, nframes);
+    if (nframes == 0) return 0;
+    if (!mag || !scores) return fail("NULL array argument");
+    for (int f0 = 0; f0 < nframes; f0 += c->max_frames) {
+        const int n = (nframes - f0 < c->max_frames) ? nframes - f0 : c->max_frames;
+        const bool dev = flags & FT8GPU_DEVICE_PTRS;
+        if (!dev && !c->d_scores) HIP_TRY(hipMalloc(&c->d_scores, (size_t)c->max_frames * kScoresPerFrame * sizeof(int16_t)));
+        const uint8_t *dm = dev ? mag + (size_t)f0 * kMagArray : c->d_mag;
+        int16_t *ds = dev ? scores + (size_t)f0 * kScoresPerFrame : c->d_scores;
+        if (!dev) HIP_TRY(hipMemcpyAsync(c->d_mag, mag + (size_t)f0 * kMagArray, (size_t)n * kMagArray, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(launch_sync(dm, c->d_lists, c->d_list_counts, ds, n, c->params.min_score, c->stream));
+        if (!dev) {
+            HIP_TRY(hipMemcpyAsync(scores + (size_t)f0 * kScoresPerFrame, ds, (size_t)n * kScoresPerFrame * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+    }
+    return 0;
+}
+
+int ft8gpu_decode_candidates(ft8gpu_ctx *c, const uint8_t *mag, const ft8gpu_candidate *cands, const int32_t *counts,
+                             int nframes, ft8gpu_decode_status *status, int flags) {
+    CHECK_COMMON(c, nframes);
+    if (nframes == 0) return 0;
+    if (!mag || !cands || !counts || !status) return fail("NULL array argument");
+    const int mc = c->params.max_candidates;
+    for (int f0 = 0; f0 < nframes; f0 += c->max_frames) {
+        const int n = (nframes - f0 < c->max_frames) ? nframes - f0 : c->max_frames;
+        const bool dev = flags & FT8GPU_DEVICE_PTRS;
+        const uint8_t *dm = dev ? mag + (size_t)f0 * kMagArray : c->d_mag;
+        const ft8gpu_candidate *dc = dev ? cands + (size_t)f0 * mc : c->d_cands;
+        const int32_t *dn = dev ? counts + f0 : c->d_counts;
+        ft8gpu_decode_status *dst = dev ? status + (size_t)f0 * mc : c->d_status;
+        if (!dev) {
+            HIP_TRY(hipMemcpyAsync(c->d_mag, mag + (size_t)f0 * kMagArray, (size_t)n * kMagArray, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->d_cands, cands + (size_t)f0 * mc, (size_t)n * mc * sizeof(ft8gpu_candidate), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->d_counts, counts + f0, n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemsetAsync(c->d_status, 0, (size_t)n * mc * sizeof(ft8gpu_decode_status), c->stream));
+        }
+        HIP_TRY(launch_decode(dm, dc, dn, dst, n, mc, c->params.ldpc_iters, c->stream));
+        if (!dev) {
+            HIP_TRY(hipMemcpyAsync(status + (size_t)f0 * mc, dst, (size_t)n * mc * sizeof(ft8gpu_decode_status), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+    }
+    return 0;
+}
+
+int ft8gpu_collect_spots(ft8gpu_ctx *c, const ft8gpu_candidate *cands, const int32_t *counts,
+                         const ft8gpu_decode_status *status, int nframes, struct decoder_results *decodes,
+                         int32_t *n_results, int flags) {
+    CHECK_COMMON(c, nframes);
+    if (nframes == 0) return 0;
+    if (!cands || !counts || !status || !decodes || !n_results) return fail("NULL array argument");
+    const int mc = c->params.max_candidates;
+    for (int f0 = 0; f0 < nframes; f0 += c->max_frames) {
+        const int n = (nframes - f0 < c->max_frames) ? nframes - f0 : c->max_frames;
+        const bool dev = flags & FT8GPU_DEVICE_PTRS;
+        if (!dev) {
+            HIP_TRY(hipMemcpyAsync(c->d_cands, cands + (size_t)f0 * mc, (size_t)n * mc * sizeof(ft8gpu_candidate), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->d_counts, counts + f0, n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->d_status, status + (size_t)f0 * mc, (size_t)n * mc * sizeof(ft8gpu_decode_status), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->d_decodes, decodes + (size_t)f0 * kMaxMessages, (size_t)n * kMaxMessages * sizeof(struct decoder_results), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(launch_spots(c->d_cands, c->d_counts, c->d_status, n, mc, c->params.min_score, c->d_decodes, c->d_nres, c->stream));
+            HIP_TRY(hipMemcpyAsync(decodes + (size_t)f0 * kMaxMessages, c->d_decodes, (size_t)n * kMaxMessages * sizeof(struct decoder_results), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(n_results + f0, c->d_nres, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        } else {
+            HIP_TRY(launch_spots(cands + (size_t)f0 * mc, counts + f0, status + (size_t)f0 * mc, n, mc, c->params.min_score,
+                                 decodes + (size_t)f0 * kMaxMessages, n_results + f0, c->stream));
+        }
+    }
+    return 0;
+}
+
+int ft8gpu_synth_frames(ft8gpu_ctx *c, const ft8gpu_synth_signal *signals, int nframes, int nsig,
+                        float noise_sigma, uint64_t seed, float *iq_dev) {
+    CHECK_COMMON(c, nframes);
+    if (nframes == 0) return 0;
+    if (nsig < 0 || nsig > 64) return fail("nsig_per_frame %d out of range [0, 64]", nsig);
+    if (!iq_dev || (nsig > 0 && !signals)) return fail("NULL array argument");
+    const size_t bytes = (size_t)nframes * (nsig > 0 ? nsig : 1) * sizeof(ft8gpu_synth_signal);
+    if (bytes > c->sigs_cap) {
+        if (c->d_sigs) (void)hipFree(c->d_sigs);
+        c->d_sigs = nullptr;
+        HIP_TRY(hipMalloc(&c->d_sigs, bytes));
+        c->sigs_cap = bytes;
+    }
+    if (nsig > 0) HIP_TRY(hipMemcpyAsync(c->d_sigs, signals, (size_t)nframes * nsig * sizeof(ft8gpu_synth_signal), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_synth(c->d_sigs, nframes, nsig, noise_sigma, seed, iq_dev, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+}  // extern "C"

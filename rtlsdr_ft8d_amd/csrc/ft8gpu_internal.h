@@ -1,0 +1,54 @@
+// ft8gpu_internal.h -- shared between the HIP translation units of libft8gpu.so (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ft8gpu.h"
+
+// rtlsdr_ft8d.h:34-56
+constexpr int kNSamples   = 48000;   // SIGNAL_LENGHT * SIGNAL_SAMPLE_RATE
+constexpr int kNfft       = 1024;    // NFFT
+constexpr int kNumBlocks  = 92;      // NUM_BLOCKS
+constexpr int kNumBin     = 256;     // NUM_BIN
+constexpr int kBlockStride = 1024;   // K_TIME_OSR * K_FREQ_OSR * NUM_BIN  (rtlsdr_ft8d.c:1446)
+constexpr int kMagArray   = 94208;   // MAG_ARRAY
+constexpr int kRowsPerFrame = 184;   // NUM_BLOCKS * K_TIME_OSR FFT rows
+constexpr int kMaxMessages = 50;     // K_MAX_MESSAGES
+
+// sync scan geometry (ft8_lib ft8_find_sync): time_offset in [-12, 24), freq_offset in [0, 249)
+constexpr int kT0Min = -12, kT0Count = 36, kF0Count = 249;
+constexpr int kSegments = 4;                                   // (time_sub, freq_sub)
+constexpr int kSyncWaves = 4;                                  // waves per sync workgroup
+constexpr int kT0PerWave = kT0Count / kSyncWaves;              // 9
+constexpr int kSublistCap = kT0PerWave * kF0Count;             // 2241 entries, worst case
+constexpr int kSublistsPerFrame = kSegments * kSyncWaves;      // 16
+constexpr int kScoresPerFrame = kSegments * kT0Count * kF0Count; // 35856
+
+constexpr int kLdpcN = 174, kLdpcK = 91, kLdpcM = 83;
+
+// waterfall kernel work decomposition
+constexpr int kWfRowsPerItem = 8;                              // FFT rows per work item
+constexpr int kWfItemsPerFrame = kRowsPerFrame / kWfRowsPerItem; // 23
+constexpr int kWfSpan = (kWfRowsPerItem - 1) * 256 + kNfft;    // 2816 samples staged per item
+
+struct Ft8Tables {                 // device-resident constant tables, built on the host at create()
+    float  hann[kNfft];            // rtlsdr_ft8d.c:331-334 (sine window)
+    float2 tw[kNfft];              // exp(-2 pi i k / 1024) = (cos, -sin), double -> float
+    float  qthr[260];              // quantiser thresholds: q(y) = #{k in 1..255 : y >= qthr[k]}
+};
+
+// kernel launchers (each enqueues on `s`, returns hipGetLastError())
+hipError_t launch_waterfall(const float *iq, uint8_t *mag, const Ft8Tables *tab, int nframes,
+                            int num_cus, hipStream_t s);
+hipError_t launch_sync(const uint8_t *mag, uint32_t *lists, int32_t *list_counts, int16_t *score_map,
+                       int nframes, int min_score, hipStream_t s);
+hipError_t launch_heap(const uint32_t *lists, const int32_t *list_counts, ft8gpu_candidate *cands,
+                       int32_t *counts, int nframes, int max_candidates, hipStream_t s);
+hipError_t launch_decode(const uint8_t *mag, const ft8gpu_candidate *cands, const int32_t *counts,
+                         ft8gpu_decode_status *status, int nframes, int max_candidates, int ldpc_iters,
+                         hipStream_t s);
+hipError_t launch_spots(const ft8gpu_candidate *cands, const int32_t *counts,
+                        const ft8gpu_decode_status *status, int nframes, int max_candidates,
+                        int min_score, struct decoder_results *decodes, int32_t *n_results, hipStream_t s);
+hipError_t launch_synth(const ft8gpu_synth_signal *sig_dev, int nframes, int nsig, float noise_sigma,
+                        uint64_t seed, float *iq, hipStream_t s);
+hipError_t decode_tables_init(hipStream_t s);   // uploads the LDPC edge tables used by the BP kernel

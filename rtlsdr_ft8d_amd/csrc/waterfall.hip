@@ -1,0 +1,198 @@
+// waterfall.hip -- stage a2+a3 of the hot path:
+//   rtlsdr_ft8d.c:1401-1411  window + 184 complex 1024-point FFTs per frame
+//   rtlsdr_ft8d.c:1413-1433  |X|^2 -> 10*log10 -> (int)(2*dB+240) clamp -> uint8, OSR de-interleave
+//
+// Design (gfx950, wave64):
+//   * persistent workgroups of 4 waves; a work item is (frame, 8 consecutive FFT rows).  The
+//     2816-sample span those rows cover is read from HBM exactly once with 16-byte coalesced loads
+//     and staged in LDS (each sample feeds up to 4 overlapping rows: hop 256, length 1024).
+//   * one wave per FFT row, 16 complex points per lane.  1024 = 16 x 16 x 4: two radix-4 stages in
+//     registers, exchange through a padded (conflict-free) LDS buffer, two more radix-4 stages,
+//     second exchange, last radix-4 stage computing only the outputs that land in bins 0..511.
+//   * window and all twiddle factors live in registers for the lifetime of the wave.
+//   * the dB quantiser is evaluated against a 256-entry threshold table derived on the host from
+//     the reference expression itself (host libm log10f), so the uint8 result is bit-identical to
+//     (int)(2*(10.0f*log10f(1e-12f + mag2*4.0f/(NFFT*NFFT)))+240); v_log_f32 only provides the
+//     first guess.
+//   * arithmetic order of the FFT is the "R4DIF-1024" order documented in DESIGN.md; compiled with
+//     -ffp-contract=off so every float operation is a single IEEE operation.
+#include "ft8gpu_internal.h"
+
+namespace {
+
+struct c32 { float r, i; };
+
+__device__ __forceinline__ c32 cmul(c32 y, float2 w) {
+    const float p1 = y.r * w.x, p2 = y.i * w.y, p3 = y.r * w.y, p4 = y.i * w.x;
+    return { p1 - p2, p3 + p4 };
+}
+
+// radix-4 DIF butterfly, forward transform: y1 = t1 - i*t3, y3 = t1 + i*t3
+__device__ __forceinline__ void bfly4(c32 &a0, c32 &a1, c32 &a2, c32 &a3) {
+    const c32 t0 = { a0.r + a2.r, a0.i + a2.i };
+    const c32 t1 = { a0.r - a2.r, a0.i - a2.i };
+    const c32 t2 = { a1.r + a3.r, a1.i + a3.i };
+    const c32 t3 = { a1.r - a3.r, a1.i - a3.i };
+    a0 = { t0.r + t2.r, t0.i + t2.i };
+    a2 = { t0.r - t2.r, t0.i - t2.i };
+    a1 = { t1.r + t3.i, t1.i - t3.r };
+    a3 = { t1.r - t3.i, t1.i + t3.r };
+}
+
+// two consecutive radix-4 stages on 16 register-resident points, register a = a_lo + 4*q
+__device__ __forceinline__ void pass16(c32 (&x)[16], const float2 (&twA)[4][3], const float2 (&twB)[3]) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        bfly4(x[a], x[a + 4], x[a + 8], x[a + 12]);
+        x[a + 4]  = cmul(x[a + 4],  twA[a][0]);
+        x[a + 8]  = cmul(x[a + 8],  twA[a][1]);
+        x[a + 12] = cmul(x[a + 12], twA[a][2]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bfly4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+        x[4 * q + 1] = cmul(x[4 * q + 1], twB[0]);
+        x[4 * q + 2] = cmul(x[4 * q + 2], twB[1]);
+        x[4 * q + 3] = cmul(x[4 * q + 3], twB[2]);
+    }
+}
+
+__device__ __forceinline__ int pad_idx(int p) { return p + 4 * (p >> 6); }
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// rtlsdr_ft8d.c:1415-1427 for one bin; qthr[k] = smallest float y with quantised value >= k
+__device__ __forceinline__ unsigned quantise(float re, float im, const float *qthr) {
+    const float mag2 = re * re + im * im;
+    const float y = 1E-12f + (mag2 * 4.0f) / 1048576.0f;
+    int k = (int)(6.0206f * __log2f(y) + 240.0f);
+    k = k < 0 ? 0 : (k > 255 ? 255 : k);
+    while (k > 0 && y < qthr[k]) --k;
+    while (k < 255 && y >= qthr[k + 1]) ++k;
+    return (unsigned)k;
+}
+
+constexpr int kXbuf = 1088;     // 1024 + 4 per 64 padding, complex entries per wave
+
+__global__ __launch_bounds__(256)
+void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ mag,
+                          const Ft8Tables *__restrict__ tab, int nitems) {
+    __shared__ __attribute__((aligned(16))) float s_in[2][kWfSpan];          // staged I and Q
+    __shared__ __attribute__((aligned(16))) float2 s_x[4][kXbuf];            // per-wave exchange
+    __shared__ __attribute__((aligned(16))) float s_thr[260];
+    __shared__ __attribute__((aligned(16))) unsigned char s_out[4][512];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    for (int i = tid; i < 260; i += 256) s_thr[i] = tab->qthr[i];
+
+    // register-resident constants: window taps and twiddles of this lane
+    float hw[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) hw[a] = tab->hann[lane + 64 * a];
+    float2 twA1[4][3], twB1[3], twA2[4][3], twB2[3];
+    const int j2 = lane & 3, b16 = lane >> 2;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int j0 = lane + 64 * a;          // stage 0: L = 1024, T = 1
+        const int jj = j2 + 4 * a;             // stage 2: L = 64,   T = 16
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            twA1[a][q - 1] = tab->tw[(q * j0) & 1023];
+            twA2[a][q - 1] = tab->tw[(q * jj * 16) & 1023];
+        }
+    }
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+        twB1[q - 1] = tab->tw[(q * lane * 4) & 1023];     // stage 1: L = 256, T = 4
+        twB2[q - 1] = tab->tw[(q * j2 * 64) & 1023];      // stage 3: L = 16,  T = 64
+    }
+
+    float2 *xb = s_x[wave];
+    unsigned char *ob = s_out[wave];
+
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int frame = item / kWfItemsPerFrame;
+        const int chunk = item - frame * kWfItemsPerFrame;
+        const float *fI = iq + (size_t)frame * (2 * kNSamples) + chunk * (kWfRowsPerItem * 256);
+        const float *fQ = fI + kNSamples;
+
+        __syncthreads();                        // previous item's readers are done with s_in
+        for (int i = tid; i < kWfSpan / 4; i += 256) {
+            reinterpret_cast<float4 *>(s_in[0])[i] = reinterpret_cast<const float4 *>(fI)[i];
+            reinterpret_cast<float4 *>(s_in[1])[i] = reinterpret_cast<const float4 *>(fQ)[i];
+        }
+        __syncthreads();
+
+#pragma unroll 1
+        for (int rr = 0; rr < kWfRowsPerItem / 4; ++rr) {
+            const int row_in_item = wave * (kWfRowsPerItem / 4) + rr;
+            const float *sI = s_in[0] + row_in_item * 256;
+            const float *sQ = s_in[1] + row_in_item * 256;
+
+            c32 x[16];
+#pragma unroll
+            for (int a = 0; a < 16; ++a) {      // rtlsdr_ft8d.c:1407-1410
+                x[a].r = sI[lane + 64 * a] * hw[a];
+                x[a].i = sQ[lane + 64 * a] * hw[a];
+            }
+            pass16(x, twA1, twB1);              // stages 0, 1
+#pragma unroll
+            for (int a = 0; a < 16; ++a) xb[pad_idx(lane + 64 * a)] = make_float2(x[a].r, x[a].i);
+            wave_lds_sync();
+#pragma unroll
+            for (int a = 0; a < 16; ++a) {
+                const float2 v = xb[pad_idx(64 * b16 + j2 + 4 * a)];
+                x[a] = { v.x, v.y };
+            }
+            pass16(x, twA2, twB2);              // stages 2, 3
+#pragma unroll
+            for (int a = 0; a < 16; ++a) xb[pad_idx(64 * b16 + j2 + 4 * a)] = make_float2(x[a].r, x[a].i);
+            wave_lds_sync();
+
+            // stage 4 (L = 4, no twiddles): butterfly c = lane + 64*i holds bins k0+i (y0) and 256+k0+i (y1)
+            unsigned q0[4], q1[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = lane + 64 * i;
+                const float4 *src = reinterpret_cast<const float4 *>(xb + pad_idx(4 * c));
+                const float4 v01 = src[0], v23 = src[1];
+                const c32 a0 = { v01.x, v01.y }, a1 = { v01.z, v01.w }, a2 = { v23.x, v23.y }, a3 = { v23.z, v23.w };
+                const c32 t0 = { a0.r + a2.r, a0.i + a2.i };
+                const c32 t1 = { a0.r - a2.r, a0.i - a2.i };
+                const c32 t2 = { a1.r + a3.r, a1.i + a3.i };
+                const c32 t3 = { a1.r - a3.r, a1.i - a3.i };
+                q0[i] = quantise(t0.r + t2.r, t0.i + t2.i, s_thr);
+                q1[i] = quantise(t1.r + t3.i, t1.i - t3.r, s_thr);
+            }
+            // bins k0..k0+3 -> [freq_sub = k&1][pos = k>>1]  (rtlsdr_ft8d.c:1420-1428)
+            const int k0 = 64 * (lane & 3) + 16 * ((lane >> 2) & 3) + 4 * (lane >> 4);
+            const int h = k0 >> 1;
+            *reinterpret_cast<unsigned short *>(ob + h)             = (unsigned short)(q0[0] | (q0[2] << 8));
+            *reinterpret_cast<unsigned short *>(ob + 256 + h)       = (unsigned short)(q0[1] | (q0[3] << 8));
+            *reinterpret_cast<unsigned short *>(ob + 128 + h)       = (unsigned short)(q1[0] | (q1[2] << 8));
+            *reinterpret_cast<unsigned short *>(ob + 256 + 128 + h) = (unsigned short)(q1[1] | (q1[3] << 8));
+            wave_lds_sync();
+            const int row = chunk * kWfRowsPerItem + row_in_item;       // = 2*idx_block + time_sub
+            uint2 *dst = reinterpret_cast<uint2 *>(mag + (size_t)frame * kMagArray + (size_t)row * 512);
+            dst[lane] = reinterpret_cast<const uint2 *>(ob)[lane];
+            wave_lds_sync();                    // ob / xb are rewritten by the next row
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_waterfall(const float *iq, uint8_t *mag, const Ft8Tables *tab, int nframes,
+                            int num_cus, hipStream_t s) {
+    const int nitems = nframes * kWfItemsPerFrame;
+    int grid = num_cus * 2;                     // 2 workgroups per CU (LDS-limited), persistent
+    if (grid > nitems) grid = nitems;
+    if (grid < 1) return hipSuccess;
+    hipLaunchKernelGGL(ft8_waterfall_kernel, dim3(grid), dim3(256), 0, s, iq, mag, tab, nitems);
+    return hipGetLastError();
+}

@@ -1,0 +1,59 @@
+"""Synthetic workload of SURVEY.md section 8(d) and the frame sharding of section 8(e).
+
+Frames are described on the host (which signals, where, how strong) and synthesised on the GPU
+(ft8gpu_synth_frames), so that a batch of thousands of 15 s frames needs no PCIe traffic.
+"""
+import numpy as np
+
+from . import SIGNAL_DTYPE, encode, pack77_std
+
+LETTERS = "ABCDEFGHIJKLMNOPQRSTUVWXYZ"
+SEED_BASE = 0x46543800            # "FT8\0", SURVEY.md section 8(d)
+
+
+def shard_range(total_frames, rank, world_size):
+    """contiguous shard [lo, hi) of `total_frames` for `rank` (frames are independent units)"""
+    base, rem = divmod(total_frames, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def message_pool(n=1024, seed=7):
+    """n distinct standard messages "CQ <call> <grid>" and their 79 tones"""
+    rng = np.random.default_rng(seed)
+    msgs, tones = [], np.zeros((n, 79), np.uint8)
+    seen = set()
+    while len(msgs) < n:
+        pfx = rng.choice(["K", "W", "N", "G", "F", "DL", "JA", "VK", "EA", "OH", "SM", "PY"])
+        call = pfx + str(rng.integers(0, 10)) + "".join(rng.choice(list(LETTERS), size=rng.integers(1, 4)))
+        if call in seen:
+            continue
+        seen.add(call)
+        grid = LETTERS[rng.integers(0, 18)] + LETTERS[rng.integers(0, 18)] + f"{rng.integers(0, 100):02d}"
+        msg = f"CQ {call} {grid}"
+        tones[len(msgs)] = encode(pack77_std(msg))
+        msgs.append(msg)
+    return msgs, tones
+
+
+def amplitude_for_snr(snr_db, noise_sigma=1.0):
+    """amplitude of a constant-envelope signal for an SNR quoted in 2500 Hz, with complex noise of
+    variance sigma^2 per component over the 3200 Hz sample bandwidth"""
+    return np.sqrt(2.0 * noise_sigma ** 2 * 2500.0 / 3200.0 * 10.0 ** (np.asarray(snr_db) / 10.0))
+
+
+def frame_signals(first_frame, nframes, nsig, pool_tones, snr_range=(-18.0, 0.0), f_range=(100.0, 1500.0),
+                  dt_range=(0.0, 1.8)):
+    """signal descriptors for global frames [first_frame, first_frame + nframes); frame g is seeded
+    with SEED_BASE + g so that any shard of any world size describes the same global batch"""
+    sig = np.zeros((nframes, max(nsig, 1)), SIGNAL_DTYPE)
+    picks = np.zeros((nframes, max(nsig, 1)), np.int32)
+    for k in range(nframes):
+        rng = np.random.default_rng(SEED_BASE + first_frame + k)
+        idx = rng.integers(0, pool_tones.shape[0], nsig)
+        sig[k, :nsig]["tones"] = pool_tones[idx]
+        sig[k, :nsig]["f0_hz"] = rng.uniform(*f_range, nsig)
+        sig[k, :nsig]["t0_s"] = rng.uniform(*dt_range, nsig)
+        sig[k, :nsig]["amplitude"] = amplitude_for_snr(rng.uniform(*snr_range, nsig))
+        picks[k, :nsig] = idx
+    return sig[:, :nsig].copy(), picks[:, :nsig]
