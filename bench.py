@@ -70,15 +70,11 @@ def main():
     dec.synth_frames(sig, B, args.nsig, 1.0, workload.SEED_BASE + lo, iq)
     spots = torch.zeros((B, ft8.MAX_MESSAGES * 28), dtype=torch.uint8, device=dev)
     nres = torch.zeros((B,), dtype=torch.int32, device=dev)
-    if world > 1:
-        all_spots = torch.empty((world * B, ft8.MAX_MESSAGES * 28), dtype=torch.uint8, device=dev)
-        all_nres = torch.empty((world * B,), dtype=torch.int32, device=dev)
 
     def step():
         dec.decode_batch_dev(iq, B, spots, nres)
         if world > 1:        # the spot list of the whole job on every rank: one RCCL all-gather each
-            dist.all_gather_into_tensor(all_spots, spots)
-            dist.all_gather_into_tensor(all_nres, nres)
+            workload.gather_spots(spots, nres, world)
 
     def fence():
         if world > 1:

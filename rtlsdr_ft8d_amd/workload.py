@@ -57,3 +57,18 @@ def frame_signals(first_frame, nframes, nsig, pool_tones, snr_range=(-18.0, 0.0)
         sig[k, :nsig]["amplitude"] = amplitude_for_snr(rng.uniform(*snr_range, nsig))
         picks[k, :nsig] = idx
     return sig[:, :nsig].copy(), picks[:, :nsig]
+
+
+def gather_spots(spots, n_results, world_size):
+    """The job's whole spot list on every rank: ONE all-gather of the fixed-size records
+    ([frames][50 x 28 B]) and one of the per-frame counts.  Works on the
+    RCCL backend (device tensors, xGMI) and on gloo (CPU tensors, used by the CPU tests).
+    Returns (all_spots [world*frames, 1400] uint8, all_counts [world*frames] int32) in global frame
+    order, because shards are contiguous and ranks are gathered in rank order."""
+    import torch
+    import torch.distributed as dist
+    all_spots = torch.empty((world_size * spots.shape[0],) + tuple(spots.shape[1:]), dtype=spots.dtype, device=spots.device)
+    all_counts = torch.empty((world_size * n_results.shape[0],), dtype=n_results.dtype, device=n_results.device)
+    dist.all_gather_into_tensor(all_spots, spots)
+    dist.all_gather_into_tensor(all_counts, n_results)
+    return all_spots, all_counts

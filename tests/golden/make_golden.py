@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.json from the CPU oracle (run from the repo root:
+`python tests/golden/make_golden.py`).
+
+What is anchored to the REFERENCE (not produced by our own code):
+  kat.json     message / packed bytes / tone string copied from the known-answer comment
+               rtlsdr_ft8d.c:919-923; everything else in that file is derived from them.
+  selftest.json "expect" block: the pass condition of decoderSelfTest(), rtlsdr_ft8d.c:966-971.
+Everything else is the oracle's own output, frozen as a regression pin ("parity unpinned" with
+respect to the absent ft8_lib sources, see oracle/ft8_oracle.h).
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import oracle_lib as O        # noqa: E402
+import synth_util as S        # noqa: E402
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def cand_list(c):
+    return [[int(x["score"]), int(x["time_offset"]), int(x["freq_offset"]), int(x["time_sub"]), int(x["freq_sub"])] for x in c]
+
+
+def spots(dec, n):
+    return [[d["call"].decode(), d["loc"].decode(), int(d["freq"]), int(d["snr"])] for d in dec[:n]]
+
+
+def main():
+    O.build()
+    # ---- KAT (reference comment) ----
+    kat = {
+        "source": "rtlsdr_ft8d.c:919-923",
+        "message": "CQ K1JT FN20QI",
+        "packed_hex": "000000204dfcdc8a1408",
+        "tones": "3140652000000001005477547106035036373140652547441342116056460065174427143140652",
+    }
+    gray = [0, 1, 3, 2, 5, 6, 4, 7]
+    inv = {t: v for v, t in enumerate(gray)}
+    data = [int(c) for c in kat["tones"][7:36] + kat["tones"][43:72]]
+    bits = [(inv[t] >> s) & 1 for t in data for s in (2, 1, 0)]
+    kat["codeword_bits"] = "".join(map(str, bits))
+    kat["crc14"] = int("".join(map(str, bits[77:91])), 2)
+    json.dump(kat, open(os.path.join(HERE, "kat.json"), "w"), indent=1)
+
+    # ---- reference self-test frame ----
+    i, q = O.selftest_signal(1)
+    mag = O.waterfall(i, q)
+    c = O.find_sync(mag)
+    dec, n = O.subsystem(i, q)
+    st = [O.decode(mag, c[k:k + 1]) for k in range(len(c))]
+    selftest = {
+        "source": "rtlsdr_ft8d.c:890-972 (glibc rand(), default seed 1)",
+        "expect": {"call": "K1JT", "loc": "FN20"},
+        "first_samples": {"I0": float(i[0]), "Q0": float(q[0]), "I1": float(i[1])},
+        "peak": float(max(np.abs(i).max(), np.abs(q).max())),
+        "iq_sha256": sha(np.stack([i, q])),
+        "waterfall": {"sha256": sha(mag), "max": int(mag.max()), "min": int(mag.min()), "mean": float(mag.mean())},
+        "candidates": cand_list(c),
+        "decode": [[s["ldpc_errors"], s["iters"], s["a91"].hex(), s["text"]] for s in st],
+        "spots": spots(dec, n), "n_results": n,
+    }
+    json.dump(selftest, open(os.path.join(HERE, "selftest.json"), "w"), indent=1)
+
+    # ---- seeded multi-signal frames (numpy synth, tests/synth_util.py) ----
+    enc = S.oracle_encode_fn(O)
+    frames = []
+    for seed, nsig, snr, cqf in [(101, 3, (-10, 0), 1.0), (102, 10, (-16, 0), 0.7), (103, 25, (-18, 0), 0.8),
+                                 (104, 45, (-20, -5), 0.6), (105, 0, (0, 0), 1.0)]:
+        iq, msgs = S.make_frame(seed, nsig, enc, snr_range=snr, cq_fraction=cqf)
+        mag = O.waterfall(iq[0], iq[1])
+        c = O.find_sync(mag)
+        st = [O.decode(mag, c[k:k + 1]) for k in range(len(c))]
+        dec, n = O.subsystem(iq[0], iq[1])
+        c480 = O.find_sync(mag, 480, 10)
+        frames.append({
+            "seed": seed, "nsig": nsig, "snr_range": list(snr), "cq_fraction": cqf, "messages": msgs,
+            "iq_sha256": sha(iq), "waterfall_sha256": sha(mag),
+            "candidates": cand_list(c), "n_candidates_cap480": len(c480), "candidates_cap480_sha256": sha(c480),
+            "decode": [[s["ldpc_errors"], s["iters"], s["a91"].hex(), s["text"]] for s in st],
+            "spots": spots(dec, n), "n_results": n,
+        })
+    json.dump({"generator": "tests/synth_util.make_frame", "frames": frames},
+              open(os.path.join(HERE, "frames.json"), "w"), indent=1)
+    print("golden written:", [f["n_results"] for f in frames])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,155 @@
+"""CPU tests of the C-ABI library: it loads, exports every symbol include/ft8gpu.h declares, its POD
+structs have the documented layout, and its host-only tooling (pack77 / encode / file readers)
+agrees with the reference KAT and the oracle.  No GPU compute is invoked here."""
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ft8():
+    import rtlsdr_ft8d_amd as m
+    if not os.path.exists(m.LIB_PATH):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "rtlsdr_ft8d_amd", "csrc"), "-j8"])
+    m.load_library()
+    return m
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "ft8gpu.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", src)
+    return sorted(set(n for n in names if n.startswith("ft8") or n in ("initFFTW", "freeFFTW")))
+
+
+def test_exports_every_declared_symbol(ft8):
+    lib = ft8.load_library()
+    names = declared_functions()
+    assert len(names) >= 28
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(ft8.ABI_SYMBOLS) == names
+    # nothing but the C ABI is exported
+    out = subprocess.check_output(["nm", "-D", "--defined-only", ft8.LIB_PATH]).decode()
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert exported == set(names)
+
+
+def test_struct_layouts(ft8):
+    """struct decoder_results: offsets 0/13/20/24, size 28 (rtlsdr_ft8d.h:136-141)"""
+    d = ft8.RESULT_DTYPE
+    assert d.itemsize == 28 and [d.fields[k][1] for k in ("call", "loc", "freq", "snr")] == [0, 13, 20, 24]
+    c = ft8.CAND_DTYPE
+    assert c.itemsize == 8 and [c.fields[k][1] for k in ("score", "time_offset", "freq_offset", "time_sub", "freq_sub")] == [0, 2, 4, 6, 7]
+    s = ft8.STATUS_DTYPE
+    assert s.itemsize == 48 and s.fields["a91"][1] == 10 and s.fields["text"][1] == 22
+    # cross-check against the C compiler's view of the header
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "ft8gpu.h"
+int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(struct decoder_results),
+ offsetof(struct decoder_results, loc), offsetof(struct decoder_results, freq), offsetof(struct decoder_results, snr),
+ sizeof(ft8gpu_candidate), sizeof(ft8gpu_decode_status), offsetof(ft8gpu_decode_status, a91),
+ offsetof(ft8gpu_decode_status, text), sizeof(ft8gpu_synth_signal)); return 0; }'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "t.c")
+        open(src, "w").write(prog)
+        exe = os.path.join(td, "t")
+        subprocess.check_call(["gcc", "-std=gnu17", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        vals = list(map(int, subprocess.check_output([exe]).split()))
+    assert vals == [28, 13, 20, 24, 8, 48, 10, 22, ft8.SIGNAL_DTYPE.itemsize]
+
+
+def test_encoder_tooling_matches_reference_kat(ft8, oracle):
+    kat = json.load(open(os.path.join(ROOT, "tests", "golden", "kat.json")))
+    p = ft8.pack77_std(kat["message"])
+    assert p.tobytes().hex() == kat["packed_hex"]
+    assert "".join(map(str, ft8.encode(p))) == kat["tones"]
+    rng = np.random.default_rng(8)
+    import synth_util as S
+    for _ in range(200):
+        msg = S.random_message(rng, cq=rng.random() < 0.5)
+        rc, po = oracle.pack77(msg)
+        assert rc == 0
+        pg = ft8.pack77_std(msg)
+        assert pg.tobytes() == po[:10].tobytes(), msg
+        assert np.array_equal(ft8.encode(pg), oracle.encode(po)), msg
+    for bad in ["", "CQ", "CQ K1JT ZZ99", "HELLO WORLD TEST", "CQ TOOLONGCALL FN20"]:
+        with pytest.raises(ValueError):
+            ft8.pack77_std(bad)
+
+
+def test_replay_file_formats(ft8, oracle, tmp_path):
+    """.iq writer/reader and .c2 reader (rtlsdr_ft8d.c:744-856) against the oracle's restatement"""
+    lib = ft8.load_library()
+    i, q = oracle.selftest_signal(1)
+    p = str(tmp_path / "a.iq").encode()
+    assert lib.ft8gpu_write_raw_iq(i.ctypes.data, q.ctypes.data, p) == 48000
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    p2 = str(tmp_path / "b.iq").encode()
+    assert oracle.lib().ft8o_write_raw_iq(fp(i), fp(q), p2) == 48000
+    assert open(p, "rb").read() == open(p2, "rb").read()
+    gi, gq = np.zeros(48000, np.float32), np.zeros(48000, np.float32)
+    oi, oq = np.zeros(48000, np.float32), np.zeros(48000, np.float32)
+    assert lib.ft8gpu_read_raw_iq(gi.ctypes.data, gq.ctypes.data, p) == 48000
+    assert oracle.lib().ft8o_read_raw_iq(fp(oi), fp(oq), p) == 48000
+    assert np.array_equal(gi, oi) and np.array_equal(gq, oq)
+    # .c2: 14-byte name, int type, double frequency, then the same payload
+    c2 = str(tmp_path / "x.c2")
+    with open(c2, "wb") as f:
+        f.write(b"210101_0000.c2"[:14].ljust(14, b"\0"))
+        f.write(np.int32(2).tobytes())
+        f.write(np.float64(14074000.0).tobytes())
+        f.write(open(p, "rb").read())
+    fr = C.c_double(0)
+    assert lib.ft8gpu_read_c2(gi.ctypes.data, gq.ctypes.data, c2.encode(), C.byref(fr)) == 48000
+    assert fr.value == 14074000.0 and np.array_equal(gi, oi) and np.array_equal(gq, oq)
+    # short file -> fewer samples reported
+    short = str(tmp_path / "s.iq")
+    open(short, "wb").write(open(p, "rb").read()[:8 * 1000])
+    assert lib.ft8gpu_read_raw_iq(gi.ctypes.data, gq.ctypes.data, short.encode()) == 1000
+    assert lib.ft8gpu_read_raw_iq(gi.ctypes.data, gq.ctypes.data, b"/nonexistent/file.iq") == 0
+
+
+def test_no_gpu_reports_error_not_fallback(ft8):
+    """without a GPU the context cannot be created and says why; nothing silently falls back"""
+    lib = ft8.load_library()
+    if lib.ft8gpu_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(ft8.Ft8GpuError):
+        ft8.Decoder(device=0, max_frames=1)
+    dec, n = ft8.ft8_subsystem(np.zeros(48000, np.float32), np.zeros(48000, np.float32))
+    assert n == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    import importlib
+    import rtlsdr_ft8d_amd as m
+    monkeypatch.setattr(m, "_lib", None)
+    monkeypatch.setattr(m, "LIB_PATH", "/nonexistent/libft8gpu.so")
+    with pytest.raises(m.Ft8GpuError):
+        m.load_library()
+
+
+def test_product_never_touches_the_oracle():
+    """the shipped package must not include, import, load or link anything under oracle/"""
+    pkg = os.path.join(ROOT, "rtlsdr_ft8d_amd")
+    pat = re.compile(r"oracle/|oracle_lib|ft8o_|libft8oracle|ft8_oracle")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".c", ".h", ".hip", ".cpp")) or fn == "Makefile":
+                txt = open(os.path.join(dirpath, fn), errors="replace").read()
+                assert not pat.search(txt), (dirpath, fn)
+    out = subprocess.check_output(["ldd", os.path.join(pkg, "libft8gpu.so")]).decode()
+    assert "oracle" not in out
+    sym = subprocess.check_output(["nm", "-D", os.path.join(pkg, "libft8gpu.so")]).decode()
+    assert "ft8o_" not in sym

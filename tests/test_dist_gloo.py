@@ -1,0 +1,92 @@
+"""world_size-2 CPU test (gloo) of the multi-GPU plumbing: contiguous frame shards, seeding that
+is independent of the world size, and the single all-gather of the spot records.  The data path
+itself has no collective (frames are independent); on the GPU box the same code runs on RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_spots(lo, hi):
+    """deterministic stand-in for a rank's decode output: record bytes depend on the global frame index"""
+    n = hi - lo
+    g = np.arange(lo, hi, dtype=np.int64)
+    spots = ((g[:, None] * 131 + np.arange(1400)[None, :] * 7) % 251).astype(np.uint8)
+    counts = (g % 50).astype(np.int32)
+    return torch.from_numpy(spots), torch.from_numpy(counts)
+
+
+def _worker(rank, world, port, total, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rtlsdr_ft8d_amd import workload
+    lo, hi = workload.shard_range(total, rank, world)
+    spots, counts = _fake_spots(lo, hi)
+    all_spots, all_counts = workload.gather_spots(spots, counts, world)
+    ref_spots, ref_counts = _fake_spots(0, total)
+    ok = bool(torch.equal(all_spots, ref_spots) and torch.equal(all_counts, ref_counts))
+    # max-over-ranks timing reduction used by bench.py
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok = ok and float(t.item()) == float(world)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok, lo, hi))
+
+
+def test_gather_spots_world2():
+    world, total = 2, 64
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [True, True]
+    assert (res[0][2], res[0][3], res[1][2], res[1][3]) == (0, 32, 32, 64)
+
+
+@pytest.mark.parametrize("total,world", [(32768, 8), (4096, 1), (10, 4), (7, 8), (0, 2)])
+def test_shard_range_covers_contiguously(total, world):
+    from rtlsdr_ft8d_amd import workload
+    edges = [workload.shard_range(total, r, world) for r in range(world)]
+    assert edges[0][0] == 0 and edges[-1][1] == total
+    assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+    sizes = [b - a for a, b in edges]
+    assert max(sizes) - min(sizes) <= 1
+
+
+def test_frame_description_independent_of_world_size():
+    """global frame g gets the same signals whichever rank of whichever world size owns it"""
+    import rtlsdr_ft8d_amd as ft8
+    from rtlsdr_ft8d_amd import workload
+    if not os.path.exists(ft8.LIB_PATH):
+        pytest.skip("libft8gpu.so not built")
+    _, tones = workload.message_pool(64)
+    whole, _ = workload.frame_signals(0, 12, 5, tones)
+    for world in (2, 3, 4):
+        parts = []
+        for r in range(world):
+            lo, hi = workload.shard_range(12, r, world)
+            parts.append(workload.frame_signals(lo, hi - lo, 5, tones)[0])
+        assert np.array_equal(np.concatenate(parts), whole)

@@ -1,0 +1,210 @@
+"""CPU tests of the oracle (test infrastructure) against the reference's own fixed points
+(tests/golden/kat.json = rtlsdr_ft8d.c:919-923, selftest.json "expect" = rtlsdr_ft8d.c:966-971)
+and against its frozen outputs (regression pins)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import synth_util as S
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def load(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return json.load(f)
+
+
+def cand_list(c):
+    return [[int(x["score"]), int(x["time_offset"]), int(x["freq_offset"]), int(x["time_sub"]), int(x["freq_sub"])] for x in c]
+
+
+# ---- reference known-answer vector -------------------------------------------------------------
+def test_kat_pack_crc_encode(oracle):
+    kat = load("kat.json")
+    rc, p = oracle.pack77(kat["message"])
+    assert rc == 0 and p[:10].tobytes().hex() == kat["packed_hex"]
+    tones = oracle.encode(p)
+    assert "".join(map(str, tones)) == kat["tones"]
+    a = bytearray(p[:10].tobytes() + b"\0\0")
+    assert oracle.crc14(bytes(a), 82) == kat["crc14"] == 0x1579
+    rc, text = oracle.unpack77(p[:10].tobytes())
+    assert rc == 0 and text == "CQ K1JT FN20"
+
+
+def test_kat_codeword_decodes_without_iterations(oracle):
+    """LLRs with the KAT codeword's signs satisfy all 83 checks at iteration 0"""
+    kat = load("kat.json")
+    bits = np.array([int(c) for c in kat["codeword_bits"]], np.float32)
+    plain, errors, iters = oracle.bp_decode((2 * bits - 1) * 4.0)
+    assert errors == 0 and iters == 0 and "".join(map(str, plain)) == kat["codeword_bits"]
+    # 12 flipped weak bits are repaired by belief propagation
+    llr = (2 * bits - 1) * 4.0
+    rng = np.random.default_rng(0)
+    bad = rng.choice(174, 12, replace=False)
+    llr[bad] *= -0.2
+    plain, errors, iters = oracle.bp_decode(llr)
+    assert errors == 0 and 0 < iters < 20 and "".join(map(str, plain)) == kat["codeword_bits"]
+
+
+# ---- reference self-test ------------------------------------------------------------------------
+def test_selftest_frame(oracle):
+    g = load("selftest.json")
+    i, q = oracle.selftest_signal(1)
+    assert abs(float(i[0]) - g["first_samples"]["I0"]) == 0 and abs(float(q[0]) - g["first_samples"]["Q0"]) == 0
+    assert sha(np.stack([i, q])) == g["iq_sha256"]
+    dec, n = oracle.subsystem(i, q)
+    # the reference's own pass condition (rtlsdr_ft8d.c:966-971): fails only if BOTH differ
+    assert not (dec[0]["call"].decode() != g["expect"]["call"] and dec[0]["loc"].decode() != g["expect"]["loc"])
+    assert dec[0]["call"] == b"K1JT" and dec[0]["loc"] == b"FN20" and n == g["n_results"] == 1
+    mag = oracle.waterfall(i, q)
+    assert sha(mag) == g["waterfall"]["sha256"]
+    c = oracle.find_sync(mag)
+    assert cand_list(c) == g["candidates"]
+    for k, exp in enumerate(g["decode"]):
+        s = oracle.decode(mag, c[k:k + 1])
+        assert [s["ldpc_errors"], s["iters"], s["a91"].hex(), s["text"]] == exp
+
+
+def test_selftest_iq_file_round_trip(oracle, tmp_path):
+    """writeRawIQfile / readRawIQfile conventions (rtlsdr_ft8d.c:744-806): interleaved, Q negated,
+    peak-normalised to 0.5 on load; the replayed frame still decodes"""
+    import ctypes as C
+    i, q = oracle.selftest_signal(1)
+    path = str(tmp_path / "selftest.iq").encode()
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    assert oracle.lib().ft8o_write_raw_iq(fp(i), fp(q), path) == 48000
+    raw = np.fromfile(path.decode(), np.float32)
+    assert raw.size == 96000 and np.array_equal(raw[0::2], i) and np.array_equal(raw[1::2], -q)
+    i2, q2 = np.zeros(48000, np.float32), np.zeros(48000, np.float32)
+    assert oracle.lib().ft8o_read_raw_iq(fp(i2), fp(q2), path) == 48000
+    assert abs(max(np.abs(i2).max(), np.abs(q2).max()) - 0.5) < 1e-6
+    dec, n = oracle.subsystem(i2, q2)
+    assert n == 1 and dec[0]["call"] == b"K1JT"
+
+
+# ---- frozen multi-signal frames -------------------------------------------------------------------
+def test_golden_frames(oracle):
+    g = load("frames.json")
+    enc = S.oracle_encode_fn(oracle)
+    for fr in g["frames"]:
+        iq, msgs = S.make_frame(fr["seed"], fr["nsig"], enc, snr_range=tuple(fr["snr_range"]), cq_fraction=fr["cq_fraction"])
+        assert msgs == fr["messages"]
+        assert sha(iq) == fr["iq_sha256"], "numpy synthesis changed: regenerate golden"
+        mag = oracle.waterfall(iq[0], iq[1])
+        assert sha(mag) == fr["waterfall_sha256"]
+        c = oracle.find_sync(mag)
+        assert cand_list(c) == fr["candidates"]
+        c480 = oracle.find_sync(mag, 480, 10)
+        assert len(c480) == fr["n_candidates_cap480"] and sha(c480) == fr["candidates_cap480_sha256"]
+        for k, exp in enumerate(fr["decode"]):
+            s = oracle.decode(mag, c[k:k + 1])
+            assert [s["ldpc_errors"], s["iters"], s["a91"].hex(), s["text"]] == exp
+        dec, n = oracle.subsystem(iq[0], iq[1])
+        got = [[d["call"].decode(), d["loc"].decode(), int(d["freq"]), int(d["snr"])] for d in dec[:n]]
+        assert n == fr["n_results"] and got == fr["spots"]
+        # every decoded CQ call was really transmitted
+        sent_calls = {m.split()[1] for m in msgs if m.startswith("CQ ")}
+        assert all(s[0] in sent_calls for s in got if s[0])
+
+
+# ---- FFT and quantiser ---------------------------------------------------------------------------
+def test_fft_matches_float64(oracle):
+    import ctypes as C
+    rng = np.random.default_rng(1)
+    x = (rng.normal(size=1024) + 1j * rng.normal(size=1024)).astype(np.complex64)
+    re, im = x.real.copy(), x.imag.copy()
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    oracle.lib().ft8o_fft1024(fp(re), fp(im))
+    ref = np.fft.fft(x.astype(np.complex128))
+    err = np.abs((re + 1j * im) - ref).max() / np.abs(ref).max()
+    assert err < 2e-6
+    # impulse at n0 -> exp(-2 pi i k n0 / N): checks direction and index order (not transpose-blind)
+    re = np.zeros(1024, np.float32)
+    im = np.zeros(1024, np.float32)
+    re[3] = 1.0
+    oracle.lib().ft8o_fft1024(fp(re), fp(im))
+    k = np.arange(1024)
+    assert np.allclose(re + 1j * im, np.exp(-2j * np.pi * k * 3 / 1024), atol=2e-6)
+
+
+def test_waterfall_float32_vs_float64(oracle):
+    i, q = oracle.selftest_signal(1)
+    a = oracle.waterfall(i, q)
+    b = oracle.waterfall(i, q, f64=True)
+    d = a.astype(int) - b.astype(int)
+    assert np.abs(d).max() <= 1 and np.count_nonzero(d) <= 10
+
+
+def test_quantiser_truncation_and_clamp(oracle):
+    q = oracle.lib().ft8o_quantise
+    assert q(0.0) == 0                       # 10*log10(1e-12) = -120 dB -> 0
+    assert q(1e30) == 255                    # clamp high
+    # 0 dB: mag2*4/2^20 = 1 -> scaled 240
+    assert q(float(2 ** 18)) == 240
+    # monotone over 30 decades
+    vals = [q(float(10.0 ** e)) for e in np.linspace(-20, 10, 400)]
+    assert all(b >= a for a, b in zip(vals, vals[1:]))
+
+
+# ---- sync search ------------------------------------------------------------------------------------
+def test_find_sync_heap_semantics(oracle):
+    """the retained multiset is the top-N of all scores >= min_score and comes out sorted"""
+    rng = np.random.default_rng(4)
+    mag = rng.integers(0, 256, 94208, dtype=np.uint8)
+    smap = oracle.score_map(mag).reshape(-1)
+    for cap, mn in [(120, 10), (7, 20), (500, 0)]:
+        c = oracle.find_sync(mag, cap, mn)
+        above = np.sort(smap[smap >= mn])[::-1]
+        assert len(c) == min(cap, above.size)
+        assert np.array_equal(np.sort(c["score"])[::-1], c["score"])          # descending
+        assert np.array_equal(c["score"], above[:len(c)])
+        for x in c[:10]:                                                     # scores agree with the map
+            s = oracle.score_map(mag)[x["time_sub"], x["freq_sub"], x["time_offset"] + 12, x["freq_offset"]]
+            assert s == x["score"]
+
+
+def test_empty_and_constant_inputs(oracle):
+    z = np.zeros(48000, np.float32)
+    dec, n = oracle.subsystem(z, z)
+    assert n == 0
+    mag = np.full(94208, 77, np.uint8)
+    assert len(oracle.find_sync(mag)) == 0
+    c = np.array([(30, 0, 10, 0, 0)], oracle.CAND_DTYPE)
+    s = oracle.decode(mag, c)                 # LLR variance 0 -> NaN -> all-zero word -> break, 83 errors
+    assert not s["ok"] and s["ldpc_errors"] == 83 and s["iters"] == 0
+
+
+# ---- unpack77 ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("msg", ["CQ K1JT FN20", "K1ABC W9XYZ EN37", "W9XYZ K1ABC -11", "K1ABC W9XYZ R-09",
+                                 "W9XYZ K1ABC RRR", "K1ABC W9XYZ RR73", "K1ABC W9XYZ 73", "QRZ DL1ABC JO62", "DE G4XYZ IO91"])
+def test_pack_unpack_round_trip(oracle, msg):
+    rc, p = oracle.pack77(msg)
+    assert rc == 0
+    rc, text = oracle.unpack77(p[:10].tobytes())
+    assert rc == 0 and text.strip() == msg
+
+
+def test_unpack_message_types(oracle):
+    def payload(i3, n3=0, body=0):
+        v = (body << 6) | (n3 << 3) | i3 if i3 == 0 else (body << 3) | i3
+        return v.to_bytes(10, "big") if False else ((v << 3).to_bytes(10, "big"))
+    # free text (i3=0,n3=0): 71-bit base-42 number; value 0 -> all blanks -> empty text
+    rc, text = oracle.unpack77(payload(0, 0, 0))
+    assert rc == 0 and text == ""
+    rc, text = oracle.unpack77(payload(0, 5, 0x123456789ABCDEF012 >> 1))
+    assert rc == 0 and len(text) == 18 and set(text) <= set("0123456789ABCDEF")
+    for n3 in (1, 2, 3, 4, 6, 7):
+        assert oracle.unpack77(payload(0, n3, 12345))[0] < 0
+    for i3 in (3, 5, 6, 7):
+        assert oracle.unpack77(payload(i3, 0, 99999))[0] < 0
+    # type 4 with icq: "CQ <call>"
+    rc, text = oracle.unpack77(payload(4, 0, (38 ** 5 + 7) << 4 | 1))
+    assert rc == 0 and text.startswith("CQ ")
