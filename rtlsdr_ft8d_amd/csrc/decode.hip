@@ -33,13 +33,16 @@ struct DecodeTables {
 __device__ DecodeTables d_tab;
 __constant__ uint8_t c_gray[8] = { 0, 1, 3, 2, 5, 6, 4, 7 };
 
+// branch-free: the rational is always evaluated (finite for every finite x) and the two clamp
+// tests of the reference select afterwards, in the reference's order
 __device__ __forceinline__ float fast_tanh(float x) {
-    if (x < -4.97f) return -1.0f;
-    if (x > 4.97f) return 1.0f;
     const float x2 = x * x;
     const float a = x * (945.0f + x2 * (105.0f + x2));
     const float b = 945.0f + x2 * (420.0f + x2 * 15.0f);
-    return __fdiv_rn(a, b);
+    float r = __fdiv_rn(a, b);
+    r = (x > 4.97f) ? 1.0f : r;
+    r = (x < -4.97f) ? -1.0f : r;
+    return r;
 }
 
 __device__ __forceinline__ float fast_atanh(float x) {
@@ -137,7 +140,7 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
     const float variance = (sum2 - (sum * sum * inv_n)) * inv_n;
     const float norm_factor = __fsqrt_rn(__fdiv_rn(24.0f, variance));
 #pragma unroll
-    for (int r = 0; r < 3; ++r) cw[r] *= norm_factor;
+    for (int r = 0; r < 3; ++r) cw[r] = has[r] ? cw[r] * norm_factor : 0.0f;
 
     // ---- per-lane constant edge data ---------------------------------------------------------
     int slot[3][3], epos[3][3];
@@ -188,33 +191,30 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
         }
 
         // messages from bits to check nodes: toc[m][n_idx] = fast_tanh(-Tnm / 2)
+        // (lanes without a third variable compute on zeros and write to the spare row 83)
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            if (has[r]) {
-                const float t0 = (cw[r] + tov[r][1]) + tov[r][2];
-                const float t1 = (cw[r] + tov[r][0]) + tov[r][2];
-                const float t2 = (cw[r] + tov[r][0]) + tov[r][1];
-                toc[slot[r][0]] = fast_tanh(-t0 / 2);
-                toc[slot[r][1]] = fast_tanh(-t1 / 2);
-                toc[slot[r][2]] = fast_tanh(-t2 / 2);
-            }
+            const float t0 = (cw[r] + tov[r][1]) + tov[r][2];
+            const float t1 = (cw[r] + tov[r][0]) + tov[r][2];
+            const float t2 = (cw[r] + tov[r][0]) + tov[r][1];
+            toc[slot[r][0]] = fast_tanh(-t0 / 2);
+            toc[slot[r][1]] = fast_tanh(-t1 / 2);
+            toc[slot[r][2]] = fast_tanh(-t2 / 2);
         }
         wave_lds_sync();
         // messages from check nodes to variable nodes: tov[n][m_idx] = -2 * fast_atanh(prod of the others)
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            if (has[r]) {
 #pragma unroll
-                for (int e = 0; e < 3; ++e) {
-                    const float4 *row = reinterpret_cast<const float4 *>(toc + (slot[r][e] & ~7));
-                    const float4 lo = row[0], hi = row[1];
-                    const float v[7] = { lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z };
-                    const int self = epos[r][e];
-                    float Tmn = 1.0f;
+            for (int e = 0; e < 3; ++e) {
+                const float4 *row = reinterpret_cast<const float4 *>(toc + (slot[r][e] & ~7));
+                const float4 lo = row[0], hi = row[1];
+                const float v[7] = { lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z };
+                const int self = epos[r][e];
+                float Tmn = 1.0f;
 #pragma unroll
-                    for (int j = 0; j < 7; ++j) Tmn *= (j == self) ? 1.0f : v[j];
-                    tov[r][e] = -2 * fast_atanh(Tmn);
-                }
+                for (int j = 0; j < 7; ++j) Tmn *= (j == self) ? 1.0f : v[j];
+                tov[r][e] = -2 * fast_atanh(Tmn);
             }
         }
         wave_lds_sync();

@@ -3,8 +3,8 @@
 // K_MAX_MESSAGES = 50 slots keyed by message.hash % 50 with strcmp on the text (:1487-1507),
 // CQ-only spot fill via strtok semantics (:1509-1518), num_decoded++ for every unique message (:1520).
 //
-// One lane per frame: the loop is inherently sequential in candidate order (first duplicate wins,
-// which fixes the reported freq / snr), tiny, and byte-oriented.
+// The table walk is inherently sequential in candidate order (first duplicate wins, which fixes the
+// reported freq / snr), tiny, and byte-oriented.
 #include "ft8gpu_internal.h"
 
 namespace {
@@ -40,61 +40,90 @@ __device__ inline void put_field(char *dst, int cap, int prec, const char *tok, 
     dst[n] = 0;
 }
 
-__global__ __launch_bounds__(64)
+// One wave per frame.  Lanes read the frame's candidate scores, `ok` flags and hashes in parallel
+// (coalesced) into LDS and reduce them to a bit mask of the candidates that reach the table code
+// (score gate :1467, ft8_decode() true :1476); lane 0 then walks only those, in candidate order,
+// through the reference's open-addressing table.  Texts are compared from HBM only on a hash match.
+__global__ __launch_bounds__(256)
 void ft8_spots_kernel(const ft8gpu_candidate *__restrict__ cands, const int32_t *__restrict__ counts,
                       const ft8gpu_decode_status *__restrict__ status, int nframes, int max_candidates,
                       int min_score, struct decoder_results *__restrict__ decodes,
                       int32_t *__restrict__ n_results) {
-    __shared__ uint16_t s_table[64][kMaxMessages + 2];     // candidate index + 1 stored per slot; 0 = empty
-    const int frame = blockIdx.x * blockDim.x + threadIdx.x;
-    if (frame >= nframes) return;
-    uint16_t *table = s_table[threadIdx.x];
-    for (int i = 0; i < kMaxMessages; ++i) table[i] = 0;                      // :1458-1460
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frame = blockIdx.x * 4 + wave;
+    if (frame >= nframes) return;                                             // wave-uniform
+    const int words = (max_candidates + 63) / 64;
+    // per wave: live mask words | hash[max_candidates] | table[50]
+    const size_t per_wave = (size_t)words * 8 + (size_t)max_candidates * 2 + 2 * (kMaxMessages + 2);
+    unsigned char *base = s_dyn + (size_t)wave * ((per_wave + 15) & ~(size_t)15);
+    unsigned long long *live = reinterpret_cast<unsigned long long *>(base);
+    uint16_t *hashes = reinterpret_cast<uint16_t *>(base + (size_t)words * 8);
+    uint16_t *table = hashes + max_candidates;
 
     const ft8gpu_candidate *fc = cands + (size_t)frame * max_candidates;
     const ft8gpu_decode_status *fs = status + (size_t)frame * max_candidates;
     struct decoder_results *out = decodes + (size_t)frame * kMaxMessages;
     const int num_candidates = counts[frame];
+
+    for (int w = 0; w < words; ++w) {
+        const int idx = w * 64 + lane;
+        bool ok = false;
+        if (idx < num_candidates) {
+            ok = fc[idx].score >= min_score && fs[idx].ok != 0;               // :1467, :1476-1485
+            hashes[idx] = fs[idx].crc_extracted;                              // message.hash
+        }
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) live[w] = m;
+    }
+    if (lane < kMaxMessages) table[lane] = 0;                                 // :1458-1460
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane != 0) return;
+
     int num_decoded = 0;
+    for (int w = 0; w < words; ++w) {
+        unsigned long long m = live[w];
+        while (m) {                                                           // :1465, candidate order
+            const int idx = w * 64 + __builtin_ctzll(m);
+            m &= m - 1;
+            const uint16_t hash = hashes[idx];
+            int idx_hash = hash % kMaxMessages;                               // :1487
+            bool found_empty_slot = false, found_duplicate = false;
+            int probes = 0;
+            do {
+                const int t = table[idx_hash];
+                if (t == 0) {
+                    found_empty_slot = true;
+                } else if (hashes[t - 1] == hash && text_equal(fs[t - 1].text, fs[idx].text)) {
+                    found_duplicate = true;
+                } else {
+                    idx_hash = (idx_hash + 1) % kMaxMessages;
+                    if (++probes >= kMaxMessages) break;  // table full: drop (reference never terminates here)
+                }
+            } while (!found_empty_slot && !found_duplicate);
 
-    for (int idx = 0; idx < num_candidates; ++idx) {                          // :1465
-        const ft8gpu_candidate cand = fc[idx];
-        if (cand.score < min_score) continue;                                 // :1467
-        if (!fs[idx].ok) continue;                                            // :1476-1485
-        const float freq_hz = (cand.freq_offset + (float)cand.freq_sub / 2) * 6.25f;   // :1470
-        const uint16_t hash = fs[idx].crc_extracted;                          // message.hash
-        int idx_hash = hash % kMaxMessages;                                   // :1487
-        bool found_empty_slot = false, found_duplicate = false;
-        int probes = 0;
-        do {
-            const int t = table[idx_hash];
-            if (t == 0) {
-                found_empty_slot = true;
-            } else if (fs[t - 1].crc_extracted == hash && text_equal(fs[t - 1].text, fs[idx].text)) {
-                found_duplicate = true;
-            } else {
-                idx_hash = (idx_hash + 1) % kMaxMessages;
-                if (++probes >= kMaxMessages) break;      // table full: drop (reference never terminates here)
+            if (found_empty_slot) {                                           // :1505
+                table[idx_hash] = (uint16_t)(idx + 1);
+                char text[25];
+                for (int i = 0; i < 25; ++i) text[i] = fs[idx].text[i];
+                text[24] = 0;
+                int pos = 0, len = 0;
+                const int t0 = next_token(text, &pos, &len);                  // :1509
+                if (t0 >= 0 && len >= 2 && text[t0] == 'C' && text[t0 + 1] == 'Q') {   // :1510 strncmp(.., "CQ", 2)
+                    const ft8gpu_candidate cand = fc[idx];
+                    const float freq_hz = (cand.freq_offset + (float)cand.freq_sub / 2) * 6.25f;   // :1470
+                    int l1 = 0, l2 = 0;
+                    const int t1 = next_token(text, &pos, &l1);
+                    put_field(out[num_decoded].call, 13, 12, t1 >= 0 ? text + t1 : nullptr, l1);   // :1512
+                    const int t2 = next_token(text, &pos, &l2);
+                    put_field(out[num_decoded].loc, 7, 6, t2 >= 0 ? text + t2 : nullptr, l2);      // :1514
+                    out[num_decoded].freq = (int32_t)freq_hz;                 // :1516
+                    out[num_decoded].snr = (int32_t)cand.score;               // :1517
+                }
+                num_decoded++;                                                // :1520
             }
-        } while (!found_empty_slot && !found_duplicate);
-
-        if (found_empty_slot) {                                               // :1505
-            table[idx_hash] = (uint16_t)(idx + 1);
-            char text[25];
-            for (int i = 0; i < 25; ++i) text[i] = fs[idx].text[i];
-            text[24] = 0;
-            int pos = 0, len = 0;
-            const int t0 = next_token(text, &pos, &len);                      // :1509
-            if (t0 >= 0 && len >= 2 && text[t0] == 'C' && text[t0 + 1] == 'Q') {   // :1510 strncmp(.., "CQ", 2)
-                int l1 = 0, l2 = 0;
-                const int t1 = next_token(text, &pos, &l1);
-                put_field(out[num_decoded].call, 13, 12, t1 >= 0 ? text + t1 : nullptr, l1);   // :1512
-                const int t2 = next_token(text, &pos, &l2);
-                put_field(out[num_decoded].loc, 7, 6, t2 >= 0 ? text + t2 : nullptr, l2);      // :1514
-                out[num_decoded].freq = (int32_t)freq_hz;                     // :1516
-                out[num_decoded].snr = (int32_t)cand.score;                   // :1517
-            }
-            num_decoded++;                                                    // :1520
         }
     }
     n_results[frame] = num_decoded;                                           // :1523
@@ -106,7 +135,9 @@ hipError_t launch_spots(const ft8gpu_candidate *cands, const int32_t *counts,
                         const ft8gpu_decode_status *status, int nframes, int max_candidates,
                         int min_score, struct decoder_results *decodes, int32_t *n_results, hipStream_t s) {
     if (nframes < 1) return hipSuccess;
-    hipLaunchKernelGGL(ft8_spots_kernel, dim3((nframes + 63) / 64), dim3(64), 0, s,
+    const int words = (max_candidates + 63) / 64;
+    const size_t per_wave = ((size_t)words * 8 + (size_t)max_candidates * 2 + 2 * (kMaxMessages + 2) + 15) & ~(size_t)15;
+    hipLaunchKernelGGL(ft8_spots_kernel, dim3((nframes + 3) / 4), dim3(256), 4 * per_wave, s,
                        cands, counts, status, nframes, max_candidates, min_score, decodes, n_results);
     return hipGetLastError();
 }

@@ -9,7 +9,8 @@
 //                    __ballot/popcount prefix sums (no atomics, no barriers after the load).
 //   ft8_heap_kernel  replays the reference's bounded min-heap (strict '>' replacement, its
 //                    heapify tie rules and the final heap sort) over the compacted list, one
-//                    frame per lane, so that candidate order is bit-identical to ft8_find_sync().
+//                    wave per frame with the heap in LDS, so that candidate order is bit-identical
+//                    to ft8_find_sync().
 #include "ft8gpu_internal.h"
 
 namespace {
@@ -81,78 +82,117 @@ void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lis
     if (lane == 0) list_counts[(size_t)frame * kSublistsPerFrame + seg * kSyncWaves + wave] = count;
 }
 
-struct __attribute__((aligned(8))) Cand { int16_t score, time_offset, freq_offset; uint8_t time_sub, freq_sub; };
+// ---- exact top-N selection -----------------------------------------------------------------
+// One wave per frame.  The min-heap lives in LDS as 64-bit words whose low 16 bits are the score
+// (the little-endian image of candidate_t).  Lanes fetch 64 list entries at a time; because the heap
+// minimum never decreases once the heap is full, entries that cannot beat the minimum seen at the
+// start of a chunk are dropped with one ballot, and only the survivors are replayed, in list order,
+// by lane 0 through the reference's insertion / eviction / heapify rules.  The final heap sort is
+// replayed the same way, so ties come out in exactly the reference's order.
+__device__ __forceinline__ int sc(uint64_t e) { return (int)(int16_t)(e & 0xFFFFu); }
 
-__device__ __forceinline__ void heapify_down(Cand *heap, int heap_size) {
+__device__ __forceinline__ void heapify_down(uint64_t *heap, int heap_size) {
     int current = 0;
+    uint64_t cur = heap[0];
     while (true) {
         int largest = current;
+        uint64_t lv = cur;
         const int left = 2 * current + 1, right = left + 1;
-        if (left < heap_size && heap[left].score < heap[largest].score) largest = left;
-        if (right < heap_size && heap[right].score < heap[largest].score) largest = right;
+        if (left < heap_size) { const uint64_t l = heap[left]; if (sc(l) < sc(lv)) { largest = left; lv = l; } }
+        if (right < heap_size) { const uint64_t r = heap[right]; if (sc(r) < sc(lv)) { largest = right; lv = r; } }
         if (largest == current) break;
-        const Cand tmp = heap[largest];
-        heap[largest] = heap[current];
-        heap[current] = tmp;
-        current = largest;
+        heap[current] = lv;                      // swap: the child value moves up ...
+        current = largest;                       // ... and `cur` continues down
     }
+    heap[current] = cur;
 }
 
-__device__ __forceinline__ void heapify_up(Cand *heap, int heap_size) {
+__device__ __forceinline__ void heapify_up(uint64_t *heap, int heap_size) {
     int current = heap_size - 1;
+    const uint64_t cur = heap[current];
     while (current > 0) {
         const int parent = (current - 1) / 2;
-        if (heap[current].score >= heap[parent].score) break;
-        const Cand tmp = heap[parent];
-        heap[parent] = heap[current];
-        heap[current] = tmp;
+        const uint64_t pv = heap[parent];
+        if (sc(cur) >= sc(pv)) break;
+        heap[current] = pv;
         current = parent;
     }
+    heap[current] = cur;
 }
 
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(256)
 void ft8_heap_kernel(const uint32_t *__restrict__ lists, const int32_t *__restrict__ list_counts,
                      ft8gpu_candidate *__restrict__ cands, int32_t *__restrict__ counts,
                      int nframes, int max_candidates) {
-    const int frame = blockIdx.x * blockDim.x + threadIdx.x;
-    if (frame >= nframes) return;
-    Cand *heap = reinterpret_cast<Cand *>(cands) + (size_t)frame * max_candidates;
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_heap_all[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frame = blockIdx.x * 4 + wave;
+    if (frame >= nframes) return;                                // wave-uniform
+    uint64_t *heap = s_heap_all + (size_t)wave * (max_candidates + 64);
+    uint64_t *stage = heap + max_candidates;                     // 64 staged survivors
     int heap_size = 0;
+
     for (int sub = 0; sub < kSublistsPerFrame; ++sub) {          // (time_sub, freq_sub, time_offset) order
         const int n = list_counts[(size_t)frame * kSublistsPerFrame + sub];
         const uint32_t *l = lists + ((size_t)frame * kSublistsPerFrame + sub) * kSublistCap;
-        const int seg = sub / kSyncWaves;
-        for (int e = 0; e < n; ++e) {
-            const uint32_t v = l[e];
-            Cand c;
-            c.score = (int16_t)(v >> 16);
-            c.time_offset = (int16_t)(((v >> 8) & 0xFF) + kT0Min);
-            c.freq_offset = (int16_t)(v & 0xFF);
-            c.time_sub = (uint8_t)(seg >> 1);
-            c.freq_sub = (uint8_t)(seg & 1);
-            if (heap_size == max_candidates && c.score > heap[0].score) {
-                heap[0] = heap[heap_size - 1];
-                --heap_size;
-                heapify_down(heap, heap_size);
+        const uint32_t seg = (uint32_t)(sub / kSyncWaves);
+        for (int base = 0; base < n; base += 64) {
+            const int e = base + lane;
+            uint64_t c = 0;
+            bool live = e < n;
+            if (live) {
+                const uint32_t v = l[e];
+                const uint32_t score = v >> 16;
+                const uint32_t t0 = (uint32_t)(int)((int)((v >> 8) & 0xFF) + kT0Min) & 0xFFFFu;
+                c = (uint64_t)score | ((uint64_t)t0 << 16) | ((uint64_t)(v & 0xFF) << 32) |
+                    ((uint64_t)(seg >> 1) << 48) | ((uint64_t)(seg & 1) << 56);
+                // prefilter against the current minimum (it can only grow while this chunk is replayed)
+                if (heap_size == max_candidates && !(sc(c) > sc(heap[0]))) live = false;
             }
-            if (heap_size < max_candidates) {
-                heap[heap_size] = c;
-                ++heap_size;
-                heapify_up(heap, heap_size);
+            const unsigned long long mask = __ballot(live);
+            if (mask == 0ull) continue;
+            if (live) stage[__popcll(mask & ((1ull << lane) - 1ull))] = c;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int m = __popcll(mask);
+            if (lane == 0) {
+                for (int i = 0; i < m; ++i) {
+                    const uint64_t cc = stage[i];
+                    if (heap_size == max_candidates && sc(cc) > sc(heap[0])) {
+                        heap[0] = heap[heap_size - 1];
+                        --heap_size;
+                        heapify_down(heap, heap_size);
+                    }
+                    if (heap_size < max_candidates) {
+                        heap[heap_size] = cc;
+                        ++heap_size;
+                        heapify_up(heap, heap_size);
+                    }
+                }
             }
+            heap_size = __shfl(heap_size, 0, 64);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
-    int len_unsorted = heap_size;
-    while (len_unsorted > 1) {
-        const Cand tmp = heap[len_unsorted - 1];
-        heap[len_unsorted - 1] = heap[0];
-        heap[0] = tmp;
-        len_unsorted--;
-        heapify_down(heap, len_unsorted);
+    if (lane == 0) {
+        int len_unsorted = heap_size;
+        while (len_unsorted > 1) {
+            const uint64_t tmp = heap[len_unsorted - 1];
+            heap[len_unsorted - 1] = heap[0];
+            heap[0] = tmp;
+            len_unsorted--;
+            heapify_down(heap, len_unsorted);
+        }
+        counts[frame] = heap_size;
     }
-    counts[frame] = heap_size;
-    const Cand zero = { 0, 0, 0, 0, 0 };
-    for (int i = heap_size; i < max_candidates; ++i) heap[i] = zero;      // deterministic tail
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint64_t *out = reinterpret_cast<uint64_t *>(cands) + (size_t)frame * max_candidates;
+    for (int i = lane; i < max_candidates; i += 64) out[i] = (i < heap_size) ? heap[i] : 0ull;   // deterministic tail
 }
 
 }  // namespace
@@ -168,7 +208,8 @@ hipError_t launch_sync(const uint8_t *mag, uint32_t *lists, int32_t *list_counts
 hipError_t launch_heap(const uint32_t *lists, const int32_t *list_counts, ft8gpu_candidate *cands,
                        int32_t *counts, int nframes, int max_candidates, hipStream_t s) {
     if (nframes < 1) return hipSuccess;
-    hipLaunchKernelGGL(ft8_heap_kernel, dim3((nframes + 63) / 64), dim3(64), 0, s,
+    const size_t lds = (size_t)4 * (max_candidates + 64) * sizeof(uint64_t);
+    hipLaunchKernelGGL(ft8_heap_kernel, dim3((nframes + 3) / 4), dim3(256), lds, s,
                        lists, list_counts, cands, counts, nframes, max_candidates);
     return hipGetLastError();
 }
