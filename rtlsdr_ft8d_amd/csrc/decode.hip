@@ -3,54 +3,115 @@
 // (ftx_normalize_logl), LDPC(174,91) sum-product decoding (bp_decode / ldpc_check / fast_tanh /
 // fast_atanh of ft8_lib ldpc.c), CRC-14 (crc.c) and unpack77 (unpack.c).
 //
-// One wave64 per candidate codeword.
+// One wave64 per candidate codeword.  The kernel is bound by the number of VALU instructions per BP
+// iteration (gfx950 issues a scalar-f32 wave64 VALU op in ~4 cycles, a packed v_pk_* op carrying
+// two results in ~5), so the iteration is organised to minimise and to pack them:
 //   * LLR: lane k < 58 owns data symbol k: 8 waterfall bytes -> three max-log differences.
 //     The values are small integers, so the reference's sequential float sums in
 //     ftx_normalize_logl (sum <= 174*255, sum of squares <= 174*255^2 < 2^24) are exact in any
 //     order; they are reduced across the wave in integer arithmetic.
-//   * BP: lane l owns variable nodes l, l+64, l+128.  Variable-to-check messages (tov) stay in
-//     registers; the check-to-variable products need the tanh terms of the other edges of a
-//     check row, which are exchanged through an 83 x 8 float LDS tile (one ds_write_b32 per edge,
-//     two ds_read_b128 per row).  Unused row slots hold 1.0f so the product loop is branch-free;
-//     multiplying by 1.0f is exact, so the product equals the reference's skip-self loop in order.
+//   * BP, variable side: lane l owns variable nodes l, l+64, l+128, i.e. 9 edges, processed as
+//     packed pairs (float2 -> v_pk_mul/add/fma_f32).  Variable-to-check messages stay in registers.
+//   * BP, check side: lane m owns check rows m and m+64.  The reference's "product of all the other
+//     edges of the row, in row order" is produced for all 7 members of a row at once from shared
+//     prefixes (25 multiplies per row, no selects); unused 7th slots hold 1.0f (x * 1.0f is exact),
+//     so every product has exactly the reference's multiplication order.
+//     Exchange goes through one 84 x 8 float LDS tile stored as two float4 planes (row-owner
+//     accesses are conflict-free ds_read/write_b128).
 //   * hard decisions are gathered with three __ballot()s; a parity check is popcount(word & row
 //     mask); the error count is the popcount of a ballot.  Exit conditions are wave-uniform.
-//   * every float expression is written in the reference's operation order and compiled with
-//     -ffp-contract=off; divisions and sqrt are IEEE correctly rounded.
+//   * divisions: the IEEE-754 correctly rounded quotient is required for parity.  The compiler's
+//     expansion is v_div_scale x2, v_rcp, fma x2, mul, fma x3 (v_div_fmas), v_div_fixup.  When
+//     v_div_scale does not rescale (|numerator| >= 2^-103, moderate denominator, quotient normal)
+//     and no special value is involved, scale and fixup are the identity and the quotient is the
+//     plain rcp/fma chain.  Denominators here lie in [60, 3e4]; a wave-uniform guard checks that
+//     every numerator driver is 0 or >= 2^-100 in magnitude and finite, and only then takes the
+//     packed rcp/fma chain (bitwise the same quotient, except that a zero quotient may carry the
+//     other sign, which no later operation can observe); otherwise the compiler's division is used.
+//   * every other float expression is written in the reference's operation order and compiled
+//     with -ffp-contract=off (fused operations appear only inside the division chain above).
 #include "ft8gpu_internal.h"
 #include "ft8_tables.h"
 #include "unpack_dev.h"
+#include <stdlib.h>
 
 namespace {
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 struct DecodeTables {
-    uint16_t edge_slot[3][64][3];     // [r][lane][m_idx] -> LDS float index m*8 + pos   (0xFFFF = no variable)
-    uint8_t  edge_pos[3][64][3];      // position of the variable inside its check row (0..6)
-    uint64_t rowmask[2][64][3];       // [r][lane][word] bit mask of the variables of check m = lane + 64 r
+    uint16_t edge_slot[3][64][3];     // [r][lane][m_idx] -> float index of slot (m, pos) in the LDS tile
+    uint64_t rowmask[2][64][3];       // [rr][lane][word] bit mask of the variables of check m = lane + 64 rr
     uint8_t  row_valid[2][64];
+    uint8_t  row_seven[2][64];        // row has 7 members (else 6: slot 6 must stay 1.0f)
 };
 
 __device__ DecodeTables d_tab;
 __constant__ uint8_t c_gray[8] = { 0, 1, 3, 2, 5, 6, 4, 7 };
 
-// branch-free: the rational is always evaluated (finite for every finite x) and the two clamp
-// tests of the reference select afterwards, in the reference's order
-__device__ __forceinline__ float fast_tanh(float x) {
-    const float x2 = x * x;
-    const float a = x * (945.0f + x2 * (105.0f + x2));
-    const float b = 945.0f + x2 * (420.0f + x2 * 15.0f);
-    float r = __fdiv_rn(a, b);
-    r = (x > 4.97f) ? 1.0f : r;
-    r = (x < -4.97f) ? -1.0f : r;
+constexpr int kRows = 84;                     // 83 check rows + 1 spare row for idle lanes
+constexpr int kTocFloats = kRows * 8;         // plane LO: [84] float4 (slots 0..3), plane HI: [84] float4 (slots 4..7)
+constexpr int kWaveLds = kTocFloats + 192;    // + 174 LLRs
+
+__host__ __device__ constexpr int slot_index(int m, int pos) {
+    return pos < 4 ? 4 * m + pos : 4 * kRows + 4 * m + (pos - 4);
+}
+
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// a / b, correctly rounded, for a pair; preconditions in the file header
+__device__ __forceinline__ f2 div_pair_fast(f2 a, f2 b) {
+    f2 r0;
+    r0.x = __builtin_amdgcn_rcpf(b.x);
+    r0.y = __builtin_amdgcn_rcpf(b.y);
+    const f2 one = { 1.0f, 1.0f };
+    const f2 e0 = pk_fma(-b, r0, one);
+    const f2 r1 = pk_fma(e0, r0, r0);
+    const f2 q0 = a * r1;
+    const f2 e1 = pk_fma(-b, q0, a);
+    const f2 q1 = pk_fma(e1, r1, q0);
+    const f2 e2 = pk_fma(-b, q1, a);
+    return pk_fma(e2, r1, q1);
+}
+
+__device__ __forceinline__ f2 div_pair_ieee(f2 a, f2 b) {
+    f2 q;
+    q.x = __fdiv_rn(a.x, b.x);
+    q.y = __fdiv_rn(a.y, b.y);
+    return q;
+}
+
+// fast_tanh() of ft8_lib ldpc.c for a pair: clamp tests in the reference's order, rational
+// evaluated unconditionally (finite for every finite x)
+template <bool FAST>
+__device__ __forceinline__ f2 tanh_pair(f2 x) {
+    const f2 x2 = x * x;
+    const f2 a = x * (945.0f + x2 * (105.0f + x2));
+    const f2 b = 945.0f + x2 * (420.0f + x2 * 15.0f);
+    f2 r = FAST ? div_pair_fast(a, b) : div_pair_ieee(a, b);
+    r.x = (x.x > 4.97f) ? 1.0f : r.x;
+    r.x = (x.x < -4.97f) ? -1.0f : r.x;
+    r.y = (x.y > 4.97f) ? 1.0f : r.y;
+    r.y = (x.y < -4.97f) ? -1.0f : r.y;
     return r;
 }
 
-__device__ __forceinline__ float fast_atanh(float x) {
-    const float x2 = x * x;
-    const float a = x * (945.0f + x2 * (-735.0f + x2 * 64.0f));
-    const float b = (945.0f + x2 * (-1050.0f + x2 * 225.0f));
-    return __fdiv_rn(a, b);
+// fast_atanh() of ft8_lib ldpc.c for a pair
+template <bool FAST>
+__device__ __forceinline__ f2 atanh_pair(f2 x) {
+    const f2 x2 = x * x;
+    const f2 a = x * (945.0f + x2 * (-735.0f + x2 * 64.0f));
+    const f2 b = (945.0f + x2 * (-1050.0f + x2 * 225.0f));
+    return FAST ? div_pair_fast(a, b) : div_pair_ieee(a, b);
 }
+
+// Guard key of a value that drives a fast division: (bits << 1) - 1 as unsigned.  Zero maps to
+// 0xFFFFFFFF, every other value to twice its magnitude bits minus one, so "the minimum key over all
+// drivers >= key(2^-100)" says: each driver is zero or at least 2^-100 in magnitude.  Large, infinite
+// and NaN drivers need no guard: |x| > 4.97 is overridden by fast_tanh's clamps in either path, the
+// row products are bounded by 1.0072^6, and NaN stays NaN through both division forms.
+__device__ __forceinline__ uint32_t guard_key(float v) { return (__float_as_uint(v) << 1) - 1u; }
+constexpr uint32_t kGuardMin = ((127u - 100u) << 24) - 1u;      // guard_key(0x1p-100f)
 
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -76,13 +137,32 @@ __device__ inline uint32_t crc14_82(const uint8_t *msg) {
     return rem & 0x3FFFu;
 }
 
-constexpr int kTocFloats = 84 * 8;        // 83 rows x 8 slots (+1 spare row)
-constexpr int kWaveLds = kTocFloats + 192;
+// bits -> checks: toc[m][n_idx] = fast_tanh(-Tnm / 2), Tnm = codeword[n] + (the other two tov, m_idx ascending)
+template <bool FAST>
+__device__ __forceinline__ void phase_tanh(const float (&x)[10], const int (&slot)[9], float *toc) {
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+        const f2 t = tanh_pair<FAST>(f2{ x[2 * p], x[2 * p + 1] });
+        toc[slot[2 * p]] = t.x;
+        if (p < 4) toc[slot[2 * p + 1]] = t.y;
+    }
+}
+
+// checks -> bits: tov[n][m_idx] = -2 * fast_atanh(product of the other toc of the row)
+template <bool FAST>
+__device__ __forceinline__ void phase_atanh(const float (&P)[10], float (&tov)[9]) {
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+        const f2 t = -2 * atanh_pair<FAST>(f2{ P[2 * p], P[2 * p + 1] });
+        tov[2 * p] = t.x;
+        if (p < 4) tov[2 * p + 1] = t.y;
+    }
+}
 
 __global__ __launch_bounds__(256)
 void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *__restrict__ cands,
                        const int32_t *__restrict__ counts, ft8gpu_decode_status *__restrict__ status,
-                       int nframes, int max_candidates, int max_iters) {
+                       int nframes, int max_candidates, int max_iters, int force_ieee_div) {
     __shared__ __attribute__((aligned(16))) float s_mem[4][kWaveLds];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -94,6 +174,8 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
 
     float *toc = s_mem[wave];
     float *llr = toc + kTocFloats;
+    float4 *planeLO = reinterpret_cast<float4 *>(toc);
+    float4 *planeHI = planeLO + kRows;
 
     const ft8gpu_candidate cand = cands[(size_t)frame * max_candidates + ci];
 
@@ -117,7 +199,7 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
         llr[3 * k + 1] = (float)l1;
         llr[3 * k + 2] = (float)l2;
     }
-    // check-row tile: padding slots stay 1.0f for the whole decode
+    // check-row tile: unused 7th / 8th slots must read 1.0f
     for (int i = lane; i < kTocFloats; i += 64) toc[i] = 1.0f;
     wave_lds_sync();
 
@@ -142,37 +224,38 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
 #pragma unroll
     for (int r = 0; r < 3; ++r) cw[r] = has[r] ? cw[r] * norm_factor : 0.0f;
 
-    // ---- per-lane constant edge data ---------------------------------------------------------
-    int slot[3][3], epos[3][3];
+    // ---- per-lane constant edge / row data ---------------------------------------------------
+    int slot[9];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int e = 0; e < 3; ++e) {
-            slot[r][e] = d_tab.edge_slot[r][lane][e];
-            epos[r][e] = d_tab.edge_pos[r][lane][e];
-        }
+        for (int e = 0; e < 3; ++e) slot[3 * r + e] = d_tab.edge_slot[r][lane][e];
     uint64_t rmask[2][3];
-    bool rvalid[2];
+    bool rvalid[2], rseven[2];
+    int rowidx[2];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        rvalid[r] = d_tab.row_valid[r][lane] != 0;
+    for (int rr = 0; rr < 2; ++rr) {
+        rvalid[rr] = d_tab.row_valid[rr][lane] != 0;
+        rseven[rr] = d_tab.row_seven[rr][lane] != 0;
+        rowidx[rr] = rvalid[rr] ? lane + 64 * rr : kRows - 1;
 #pragma unroll
-        for (int w = 0; w < 3; ++w) rmask[r][w] = d_tab.rowmask[r][lane][w];
+        for (int w = 0; w < 3; ++w) rmask[rr][w] = d_tab.rowmask[rr][lane][w];
     }
 
     // ---- bp_decode ---------------------------------------------------------------------------
-    float tov[3][3];
+    float tov[9];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) tov[r][0] = tov[r][1] = tov[r][2] = 0.0f;
+    for (int i = 0; i < 9; ++i) tov[i] = 0.0f;
     int min_errors = kLdpcM;
     uint64_t B0 = 0, B1 = 0, B2 = 0;
     int iter = 0;
+    const uint32_t guard_min = force_ieee_div ? 0xFFFFFFFFu : kGuardMin;     // debug: always take the compiler's division
     for (; iter < max_iters; ++iter) {
         // hard decision (tov = 0 in iteration 0)
         bool bit[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
-            bit[r] = has[r] && ((((cw[r] + tov[r][0]) + tov[r][1]) + tov[r][2]) > 0.0f);
+            bit[r] = has[r] && ((((cw[r] + tov[3 * r]) + tov[3 * r + 1]) + tov[3 * r + 2]) > 0.0f);
         B0 = __ballot(bit[0]);
         B1 = __ballot(bit[1]);
         B2 = __ballot(bit[2]);
@@ -181,43 +264,69 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
         // ldpc_check
         int errors = 0;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int par = (__popcll(B0 & rmask[r][0]) + __popcll(B1 & rmask[r][1]) + __popcll(B2 & rmask[r][2])) & 1;
-            errors += __popcll(__ballot(rvalid[r] && par));
+        for (int rr = 0; rr < 2; ++rr) {
+            const int par = (__popcll(B0 & rmask[rr][0]) + __popcll(B1 & rmask[rr][1]) + __popcll(B2 & rmask[rr][2])) & 1;
+            errors += __popcll(__ballot(rvalid[rr] && par));
         }
         if (errors < min_errors) {
             min_errors = errors;
             if (errors == 0) break;
         }
 
-        // messages from bits to check nodes: toc[m][n_idx] = fast_tanh(-Tnm / 2)
-        // (lanes without a third variable compute on zeros and write to the spare row 83)
+        // ---- bits -> checks ------------------------------------------------------------------
+        // (lanes without a third variable compute on zeros and write to the spare row)
+        float x[10];
+        uint32_t gmin = 0xFFFFFFFFu;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const float t0 = (cw[r] + tov[r][1]) + tov[r][2];
-            const float t1 = (cw[r] + tov[r][0]) + tov[r][2];
-            const float t2 = (cw[r] + tov[r][0]) + tov[r][1];
-            toc[slot[r][0]] = fast_tanh(-t0 / 2);
-            toc[slot[r][1]] = fast_tanh(-t1 / 2);
-            toc[slot[r][2]] = fast_tanh(-t2 / 2);
+            const float u = cw[r] + tov[3 * r];
+            const float t0 = (cw[r] + tov[3 * r + 1]) + tov[3 * r + 2];
+            const float t1 = u + tov[3 * r + 2];
+            const float t2 = u + tov[3 * r + 1];
+            x[3 * r + 0] = -t0 / 2;
+            x[3 * r + 1] = -t1 / 2;
+            x[3 * r + 2] = -t2 / 2;
+        }
+        x[9] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) gmin = min(gmin, guard_key(x[i]));
+        if (__all(gmin >= guard_min) && !force_ieee_div) phase_tanh<true>(x, slot, toc);
+        else phase_tanh<false>(x, slot, toc);
+        wave_lds_sync();
+
+        // ---- check rows: ordered products that skip one member, for all members ---------------
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const float4 lo = planeLO[rowidx[rr]], hi = planeHI[rowidx[rr]];
+            const float v0 = lo.x, v1 = lo.y, v2 = lo.z, v3 = lo.w, v4 = hi.x, v5 = hi.y, v6 = hi.z;
+            const f2 o01 = ((((f2{ v1, v0 } * v2) * v3) * v4) * v5) * v6;   // skip 0 | skip 1
+            const float p2 = v0 * v1;
+            const float p3 = p2 * v2;
+            const float p4 = p3 * v3;
+            const float p5 = p4 * v4;
+            const float o2 = (((p2 * v3) * v4) * v5) * v6;
+            const float o3 = ((p3 * v4) * v5) * v6;
+            const float o4 = (p4 * v5) * v6;
+            const float o5 = p5 * v6;
+            const float o6 = rseven[rr] ? p5 * v5 : 1.0f;                    // 6-member rows keep 1.0f in slot 6
+            planeLO[rowidx[rr]] = make_float4(o01.x, o01.y, o2, o3);
+            planeHI[rowidx[rr]] = make_float4(o4, o5, o6, 1.0f);
         }
         wave_lds_sync();
-        // messages from check nodes to variable nodes: tov[n][m_idx] = -2 * fast_atanh(prod of the others)
+
+        // ---- checks -> bits ------------------------------------------------------------------
+        float P[10];
+        gmin = 0xFFFFFFFFu;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-#pragma unroll
-            for (int e = 0; e < 3; ++e) {
-                const float4 *row = reinterpret_cast<const float4 *>(toc + (slot[r][e] & ~7));
-                const float4 lo = row[0], hi = row[1];
-                const float v[7] = { lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z };
-                const int self = epos[r][e];
-                float Tmn = 1.0f;
-#pragma unroll
-                for (int j = 0; j < 7; ++j) Tmn *= (j == self) ? 1.0f : v[j];
-                tov[r][e] = -2 * fast_atanh(Tmn);
-            }
+        for (int i = 0; i < 9; ++i) {
+            const float v = toc[slot[i]];
+            P[i] = (i < 6 || has[2]) ? v : 0.0f;                 // idle lanes: zeros, so they never trip the guard
+            gmin = min(gmin, guard_key(P[i]));
         }
-        wave_lds_sync();
+        P[9] = 0.0f;
+        if (__all(gmin >= guard_min) && !force_ieee_div) phase_atanh<true>(P, tov);
+        else phase_atanh<false>(P, tov);
+        // (the next iteration's toc stores hit only this lane's own slots; LDS is in order per wave)
     }
 
     // ---- pack_bits / CRC / unpack77 (one lane) -----------------------------------------------
@@ -266,24 +375,24 @@ hipError_t decode_tables_init(hipStream_t s) {
         for (int l = 0; l < 64; ++l) {
             const int n = l + 64 * r;
             for (int e = 0; e < 3; ++e) {
-                if (n >= kLdpcN) { h.edge_slot[r][l][e] = (uint16_t)(83 * 8 + e); h.edge_pos[r][l][e] = 7; continue; }
+                if (n >= kLdpcN) { h.edge_slot[r][l][e] = (uint16_t)slot_index(kRows - 1, e); continue; }
                 const int m = kFT8_Mn[n][e] - 1;
                 int pos = -1;
                 for (int j = 0; j < kFT8_Num_rows[m]; ++j)
                     if (kFT8_Nm[m][j] - 1 == n) pos = j;
-                h.edge_slot[r][l][e] = (uint16_t)(m * 8 + pos);
-                h.edge_pos[r][l][e] = (uint8_t)pos;
+                h.edge_slot[r][l][e] = (uint16_t)slot_index(m, pos);
             }
         }
-    for (int r = 0; r < 2; ++r)
+    for (int rr = 0; rr < 2; ++rr)
         for (int l = 0; l < 64; ++l) {
-            const int m = l + 64 * r;
-            h.row_valid[r][l] = m < kLdpcM;
-            h.rowmask[r][l][0] = h.rowmask[r][l][1] = h.rowmask[r][l][2] = 0;
+            const int m = l + 64 * rr;
+            h.row_valid[rr][l] = m < kLdpcM;
+            h.row_seven[rr][l] = (m < kLdpcM) ? (kFT8_Num_rows[m] == 7) : 1;
+            h.rowmask[rr][l][0] = h.rowmask[rr][l][1] = h.rowmask[rr][l][2] = 0;
             if (m >= kLdpcM) continue;
             for (int j = 0; j < kFT8_Num_rows[m]; ++j) {
                 const int n = kFT8_Nm[m][j] - 1;
-                h.rowmask[r][l][n >> 6] |= 1ull << (n & 63);
+                h.rowmask[rr][l][n >> 6] |= 1ull << (n & 63);
             }
         }
     return hipMemcpyToSymbolAsync(HIP_SYMBOL(d_tab), &h, sizeof(h), 0, hipMemcpyHostToDevice, s);
@@ -292,10 +401,13 @@ hipError_t decode_tables_init(hipStream_t s) {
 hipError_t launch_decode(const uint8_t *mag, const ft8gpu_candidate *cands, const int32_t *counts,
                          ft8gpu_decode_status *status, int nframes, int max_candidates, int ldpc_iters,
                          hipStream_t s) {
+    // FT8GPU_FORCE_IEEE_DIV=1 routes every BP division through the compiler's IEEE expansion (the
+    // path the guard falls back to); used by the parity tests to cover that path
+    static const int force_ieee_div = [] { const char *e = getenv("FT8GPU_FORCE_IEEE_DIV"); return (e && e[0] == '1') ? 1 : 0; }();
     if (nframes < 1) return hipSuccess;
     const long nwaves = (long)nframes * max_candidates;
     const unsigned grid = (unsigned)((nwaves + 3) / 4);
     hipLaunchKernelGGL(ft8_decode_kernel, dim3(grid), dim3(256), 0, s,
-                       mag, cands, counts, status, nframes, max_candidates, ldpc_iters);
+                       mag, cands, counts, status, nframes, max_candidates, ldpc_iters, force_ieee_div);
     return hipGetLastError();
 }

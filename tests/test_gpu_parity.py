@@ -355,3 +355,39 @@ def test_device_synth_frames_decode_and_match_oracle(oracle):
         calls = {x["call"].decode() for x in dec[b][:n[b]]}
         found += sum(1 for bb, m in sent if bb == b and m.split()[1] in calls)
     assert found >= 0.6 * len(sent)        # most of the planted CQ calls are recovered
+
+
+def test_decode_with_forced_ieee_division(oracle, frames, oracle_mags):
+    """the BP kernel's guarded fast division falls back to the compiler's IEEE division when a
+    numerator is tiny; FT8GPU_FORCE_IEEE_DIV=1 takes that path for every division.  Run in a child
+    process (the switch is read once per process) and compare against the oracle again."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import oracle_lib as O, synth_util as S, rtlsdr_ft8d_amd as ft8
+enc = S.oracle_encode_fn(O)
+frames = [np.stack(O.selftest_signal())] + [S.make_frame(s, n, enc, snr_range=(-18, 0), cq_fraction=0.7)[0] for s, n in [(13, 20), (14, 40), (16, 12)]]
+iq = np.stack(frames)
+with ft8.Decoder(device=0, max_frames=4) as d:
+    mag = d.waterfall(iq)
+    cands, counts = d.find_sync(mag)
+    st = d.decode_candidates(mag, cands, counts)
+    dec, n = d.decode_batch(iq)
+bad = 0
+for k in range(iq.shape[0]):
+    for c in range(counts[k]):
+        r = O.decode(mag[k], cands[k, c:c + 1], 20)
+        g = st[k, c]
+        bad += not (g['ldpc_errors'] == r['ldpc_errors'] and g['iters'] == r['iters'] and bytes(g['a91']) == r['a91'] and bool(g['ok']) == r['ok'])
+    rdec, rn = O.subsystem(iq[k, 0], iq[k, 1])
+    bad += not (n[k] == rn and dec[k].tobytes() == rdec.tobytes())
+print('BAD', bad, 'CANDS', int(counts.sum()))
+"""
+    env = dict(os.environ, FT8GPU_FORCE_IEEE_DIV="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "BAD 0 CANDS" in out.stdout, out.stdout[-500:]
