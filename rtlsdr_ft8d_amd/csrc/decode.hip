@@ -165,7 +165,8 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
                        int nframes, int max_candidates, int max_iters, int force_ieee_div) {
     __shared__ __attribute__((aligned(16))) float s_mem[4][kWaveLds];
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform by construction: keep it in an SGPR
     const long gw = (long)blockIdx.x * 4 + wave;
     const int frame = (int)(gw / max_candidates);
     const int ci = (int)(gw - (long)frame * max_candidates);

@@ -17,10 +17,10 @@ constexpr int kMaxMessages = 50;     // K_MAX_MESSAGES
 // sync scan geometry (ft8_lib ft8_find_sync): time_offset in [-12, 24), freq_offset in [0, 249)
 constexpr int kT0Min = -12, kT0Count = 36, kF0Count = 249;
 constexpr int kSegments = 4;                                   // (time_sub, freq_sub)
-constexpr int kSyncWaves = 4;                                  // waves per sync workgroup
-constexpr int kT0PerWave = kT0Count / kSyncWaves;              // 9
-constexpr int kSublistCap = kT0PerWave * kF0Count;             // 2241 entries, worst case
-constexpr int kSublistsPerFrame = kSegments * kSyncWaves;      // 16
+constexpr int kSyncWaves = 8;                                  // waves per sync workgroup
+constexpr int kT0PerWaveMax = (kT0Count + kSyncWaves - 1) / kSyncWaves;   // 5 (waves get 4 or 5 time offsets)
+constexpr int kSublistCap = kT0PerWaveMax * kF0Count;          // 1245 entries, worst case
+constexpr int kSublistsPerFrame = kSegments * kSyncWaves;      // 32
 constexpr int kScoresPerFrame = kSegments * kT0Count * kF0Count; // 35856
 
 constexpr int kLdpcN = 174, kLdpcK = 91, kLdpcM = 83;

@@ -50,7 +50,8 @@ void ft8_spots_kernel(const ft8gpu_candidate *__restrict__ cands, const int32_t 
                       int min_score, struct decoder_results *__restrict__ decodes,
                       int32_t *__restrict__ n_results) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform by construction: keep it in an SGPR
     const int frame = blockIdx.x * 4 + wave;
     if (frame >= nframes) return;                                             // wave-uniform
     const int words = (max_candidates + 63) / 64;

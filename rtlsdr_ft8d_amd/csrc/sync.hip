@@ -3,10 +3,12 @@
 //
 // Two kernels:
 //   ft8_sync_kernel  one workgroup per (frame, time_sub, freq_sub): stages that 92x256-byte slice
-//                    of the waterfall in LDS, scores all 36 x 249 (time_offset, freq_offset)
-//                    positions with the integer Costas neighbour-contrast score, and compacts the
-//                    positions with score >= min_score, in the reference's scan order, with
-//                    __ballot/popcount prefix sums (no atomics, no barriers after the load).
+//                    of the waterfall in LDS, derives a 5-point-stencil int16 map from it (the
+//                    score of 12 of the 21 sync symbols is then a single LDS read), scores all
+//                    36 x 249 (time_offset, freq_offset) positions with the integer Costas
+//                    neighbour-contrast score, and compacts the positions with score >= min_score,
+//                    in the reference's scan order, with __ballot/popcount prefix sums (no atomics,
+//                    no barriers after the map is built).
 //   ft8_heap_kernel  replays the reference's bounded min-heap (strict '>' replacement, its
 //                    heapify tie rules and the final heap sort) over the compacted list, one
 //                    wave per frame with the heap in LDS, so that candidate order is bit-identical
@@ -15,61 +17,141 @@
 
 namespace {
 
-__constant__ uint8_t c_costas[7] = { 3, 1, 4, 0, 6, 5, 2 };
+// LDS layout of one (frame, time_sub, freq_sub) slice, in this order, one allocation:
+//   guard (13 rows of bytes) | P: uint8 [92][256] waterfall slice | S5: int16 [92][256] stencil map | guard (10 int16 rows)
+// A sync symbol at an out-of-range block (b < 0 or b >= 92) is addressed like any other, lands in a
+// guard or in the neighbouring map, and is multiplied by a wave-uniform weight of 0 -- so every LDS
+// read of a position has a compile-time offset from one base register and no address arithmetic.
+constexpr int kPitch = 256;                              // bytes per waterfall row
+constexpr int kSPitch = 256;                             // int16 per stencil row
+constexpr int kGuardP = 13 * kPitch;                     // rows -13..-1 (b - 1 for b = t0 = -12)
+constexpr int kOffP = kGuardP;
+constexpr int kOffS = kOffP + kNumBlocks * kPitch;       // byte offset of S5
+constexpr int kGuardS = 10 * kSPitch * 2;
+constexpr int kSyncLds = kOffS + kNumBlocks * kSPitch * 2 + kGuardS;   // 79104 bytes: two workgroups per CU
 
-constexpr int kSliceRows = kNumBlocks;                  // 92 rows of 256 bytes
-constexpr int kSlicePitch = 256 + 16;                   // bytes; +16 keeps rows 16-byte aligned and
-                                                        // staggers rows across LDS banks
+// Contribution of one sync symbol (Costas index K, tone column C) of ft8_sync_score() at absolute
+// block b = t0 + 36 m + K (wave-uniform) and bin column f0 + C.  For K in {1,2,4,5} all four
+// neighbour terms exist away from the first/last block, and the whole contribution is one read of
+// the 5-point stencil map
+//   S5[b][f] = (p-p[f-1]) + (p-p[f+1]) + [b>0](p-p[b-1][f]) + [b<91](p-p[b+1][f]),
+// whose boundary rows already omit the missing time neighbour exactly as the reference does.
+// K = 0 has no earlier sync symbol, K = 6 no later one, and K = 3 (tone 0) no lower bin.
+// pb / sb point at (row t0, column f0) of P / S5; everything that depends on b is a scalar weight.
+template <int K, int C>
+__device__ __forceinline__ int sync_symbol(const uint8_t *pb, const int16_t *sb, int t0) {
+    int acc = 0;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const int rel = 36 * m + K;                                      // compile-time row offset from t0
+        const int b = t0 + rel;                                          // wave-uniform
+        const int w = (b >= 0 && b < kNumBlocks) ? 1 : 0;
+        if (K == 1 || K == 2 || K == 4 || K == 5) {
+            acc += w * (int)sb[rel * kSPitch + C];
+        } else {
+            const int c = pb[rel * kPitch + C];
+            int t = c - pb[rel * kPitch + C + 1];
+            if (C > 0) t += c - pb[rel * kPitch + C - 1];
+            acc += w * t;
+            if (K > 0) {
+                const int wm = (w && b > 0) ? 1 : 0;
+                acc += wm * (c - (int)pb[(rel - 1) * kPitch + C]);
+            }
+            if (K < 6) {
+                const int wp = (w && b + 1 < kNumBlocks) ? 1 : 0;
+                acc += wp * (c - (int)pb[(rel + 1) * kPitch + C]);
+            }
+        }
+    }
+    return acc;
+}
 
-__global__ __launch_bounds__(256)
+// number of neighbour terms ft8_sync_score() averages over, for time offset t0 (independent of f0)
+__device__ __forceinline__ int sync_navg(int t0) {
+    int n = 0;
+    for (int m = 0; m < 3; ++m)
+        for (int k = 0; k < 7; ++k) {
+            const int b = t0 + 36 * m + k;
+            if (b < 0) continue;
+            if (b >= kNumBlocks) break;
+            n += (k != 3) + 1;                          // sm > 0 ; sm < 7 always (Costas tones are 0..6)
+            n += (k > 0 && b > 0);
+            n += (k + 1 < 7 && b + 1 < kNumBlocks);
+        }
+    return n;
+}
+
+__global__ __launch_bounds__(64 * kSyncWaves)
 void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lists,
                      int32_t *__restrict__ list_counts, int16_t *__restrict__ score_map, int min_score) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_wf[kSliceRows * kSlicePitch];
+    __shared__ __attribute__((aligned(16))) uint8_t s_lds[kSyncLds];
+    uint8_t *s_wf = s_lds + kOffP;
+    int16_t *s_s5 = reinterpret_cast<int16_t *>(s_lds + kOffS);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: keep it in an SGPR
     const int frame = blockIdx.x >> 2, seg = blockIdx.x & 3;
     const int ts = seg >> 1, fs = seg & 1;
 
     // mag[block][time_sub][freq_sub][bin]: one 256-byte run per block for this (ts, fs)
     const uint8_t *src = mag + (size_t)frame * kMagArray + ts * 512 + fs * 256;
-    for (int i = tid; i < kSliceRows * 16; i += 256) {
+    for (int i = tid; i < kNumBlocks * 16; i += 64 * kSyncWaves) {
         const int row = i >> 4, col = (i & 15) * 16;
-        *reinterpret_cast<uint4 *>(s_wf + row * kSlicePitch + col) =
+        *reinterpret_cast<uint4 *>(s_wf + row * kPitch + col) =
             *reinterpret_cast<const uint4 *>(src + (size_t)row * kBlockStride + col);
     }
     __syncthreads();
+    // 5-point stencil map, four cells per thread from dword reads; columns 0 and 255 are never
+    // addressed by a tone that has both bin neighbours and are left 0
+    for (int i = tid; i < kNumBlocks * 64; i += 64 * kSyncWaves) {
+        const int row = i >> 6, col = (i & 63) * 4;
+        const uint8_t *p = s_wf + row * kPitch + col;
+        const uint32_t mid = *reinterpret_cast<const uint32_t *>(p);
+        const uint32_t up = row > 0 ? *reinterpret_cast<const uint32_t *>(p - kPitch) : mid;              // missing neighbour:
+        const uint32_t dn = row + 1 < kNumBlocks ? *reinterpret_cast<const uint32_t *>(p + kPitch) : mid;  // p - p = 0
+        const int left = col > 0 ? p[-1] : 0, right = col + 4 < 256 ? p[4] : 0;
+        int c[6];
+        c[0] = left;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j + 1] = (mid >> (8 * j)) & 0xFF;
+        c[5] = right;
+        int v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cc = c[j + 1];
+            v[j] = (cc - c[j]) + (cc - c[j + 2]) + (cc - (int)((up >> (8 * j)) & 0xFF)) + (cc - (int)((dn >> (8 * j)) & 0xFF));
+        }
+        if (col == 0) v[0] = 0;
+        if (col == 252) v[3] = 0;
+        uint2 packed;
+        packed.x = (uint32_t)(v[0] & 0xFFFF) | ((uint32_t)v[1] << 16);
+        packed.y = (uint32_t)(v[2] & 0xFFFF) | ((uint32_t)v[3] << 16);
+        *reinterpret_cast<uint2 *>(s_s5 + row * kSPitch + col) = packed;
+    }
+    __syncthreads();
 
-    uint32_t *my_list = lists + ((size_t)frame * kSublistsPerFrame + seg * kSyncWaves + wave) * kSublistCap;
+    const int sub = seg * kSyncWaves + wave;
+    uint32_t *my_list = lists + ((size_t)frame * kSublistsPerFrame + sub) * kSublistCap;
     int count = 0;
+    const int t_begin = (wave * kT0Count) / kSyncWaves, t_end = ((wave + 1) * kT0Count) / kSyncWaves;
 
-    for (int r = 0; r < kT0PerWave; ++r) {
-        const int t0i = wave * kT0PerWave + r;          // scan order: time_offset ascending
+    for (int t0i = t_begin; t0i < t_end; ++t0i) {        // scan order: time_offset ascending
         const int t0 = t0i + kT0Min;
+        const int navg = sync_navg(t0);
 #pragma unroll 1
         for (int pass = 0; pass < 4; ++pass) {
             const int f0 = pass * 64 + lane;            // then freq_offset ascending
             const bool valid = f0 < kF0Count;
-            int score = 0, navg = 0;
-            if (valid) {
-                // ft8_sync_score(): neighbours of the expected Costas tone, frequency- and time-wise
-                for (int m = 0; m < 3; ++m) {
-                    for (int k = 0; k < 7; ++k) {
-                        const int block_abs = t0 + 36 * m + k;
-                        if (block_abs < 0) continue;
-                        if (block_abs >= kNumBlocks) break;
-                        const int sm = c_costas[k];
-                        const uint8_t *p8 = s_wf + block_abs * kSlicePitch + f0;
-                        const int c = p8[sm];
-                        if (sm > 0) { score += c - p8[sm - 1]; ++navg; }
-                        if (sm < 7) { score += c - p8[sm + 1]; ++navg; }
-                        if (k > 0 && block_abs > 0) { score += c - p8[sm - kSlicePitch]; ++navg; }
-                        if (k + 1 < 7 && block_abs + 1 < kNumBlocks) { score += c - p8[sm + kSlicePitch]; ++navg; }
-                    }
-                }
-                if (navg > 0) score /= navg;            // C int division, truncates toward zero
-                if (score_map)
-                    score_map[(size_t)frame * kScoresPerFrame + (seg * kT0Count + t0i) * kF0Count + f0] = (int16_t)score;
-            }
+            const int fc = valid ? f0 : 0;
+            const uint8_t *pb = s_wf + t0 * kPitch + fc;
+            const int16_t *sb = s_s5 + t0 * kSPitch + fc;
+            // Costas pattern {3,1,4,0,6,5,2}
+            int score = sync_symbol<0, 3>(pb, sb, t0) + sync_symbol<1, 1>(pb, sb, t0) + sync_symbol<2, 4>(pb, sb, t0) +
+                        sync_symbol<3, 0>(pb, sb, t0) + sync_symbol<4, 6>(pb, sb, t0) + sync_symbol<5, 5>(pb, sb, t0) +
+                        sync_symbol<6, 2>(pb, sb, t0);
+            if (navg > 0) score /= navg;                // C int division, truncates toward zero
+            if (valid && score_map)
+                score_map[(size_t)frame * kScoresPerFrame + (seg * kT0Count + t0i) * kF0Count + f0] = (int16_t)score;
             const bool keep = valid && score >= min_score;
             const unsigned long long mask = __ballot(keep);
             if (keep) {
@@ -79,7 +161,7 @@ void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lis
             count += __popcll(mask);
         }
     }
-    if (lane == 0) list_counts[(size_t)frame * kSublistsPerFrame + seg * kSyncWaves + wave] = count;
+    if (lane == 0) list_counts[(size_t)frame * kSublistsPerFrame + sub] = count;
 }
 
 // ---- exact top-N selection -----------------------------------------------------------------
@@ -125,7 +207,8 @@ void ft8_heap_kernel(const uint32_t *__restrict__ lists, const int32_t *__restri
                      ft8gpu_candidate *__restrict__ cands, int32_t *__restrict__ counts,
                      int nframes, int max_candidates) {
     extern __shared__ __attribute__((aligned(16))) uint64_t s_heap_all[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform by construction: keep it in an SGPR
     const int frame = blockIdx.x * 4 + wave;
     if (frame >= nframes) return;                                // wave-uniform
     uint64_t *heap = s_heap_all + (size_t)wave * (max_candidates + 64);
@@ -200,7 +283,7 @@ void ft8_heap_kernel(const uint32_t *__restrict__ lists, const int32_t *__restri
 hipError_t launch_sync(const uint8_t *mag, uint32_t *lists, int32_t *list_counts, int16_t *score_map,
                        int nframes, int min_score, hipStream_t s) {
     if (nframes < 1) return hipSuccess;
-    hipLaunchKernelGGL(ft8_sync_kernel, dim3(nframes * kSegments), dim3(256), 0, s,
+    hipLaunchKernelGGL(ft8_sync_kernel, dim3(nframes * kSegments), dim3(64 * kSyncWaves), 0, s,
                        mag, lists, list_counts, score_map, min_score);
     return hipGetLastError();
 }

@@ -86,7 +86,8 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
     __shared__ __attribute__((aligned(16))) float s_thr[260];
     __shared__ __attribute__((aligned(16))) unsigned char s_out[4][512];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: keep it in an SGPR
 
     for (int i = tid; i < 260; i += 256) s_thr[i] = tab->qthr[i];
 
