@@ -66,17 +66,32 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // rtlsdr_ft8d.c:1415-1427 for one bin; qthr[k] = smallest float y with quantised value >= k
+// (qthr[0] = 0, qthr[256] = +inf).  v_log_f32 (1 ulp) puts the guess 6.0206*log2(y)+240 within
+// 1e-2 of the reference's float expression, so the truncated guess is off by at most one step and a
+// single comparison against the two neighbouring thresholds makes it exact -- branch-free, with
+// both table reads of all eight bins of a lane in flight together.
 __device__ __forceinline__ unsigned quantise(float re, float im, const float *qthr) {
     const float mag2 = re * re + im * im;
     const float y = 1E-12f + (mag2 * 4.0f) / 1048576.0f;
     int k = (int)(6.0206f * __log2f(y) + 240.0f);
     k = k < 0 ? 0 : (k > 255 ? 255 : k);
-    while (k > 0 && y < qthr[k]) --k;
-    while (k < 255 && y >= qthr[k + 1]) ++k;
+    const float t0 = qthr[k], t1 = qthr[k + 1];
+    k += (y >= t1 ? 1 : 0) - (y < t0 ? 1 : 0);
     return (unsigned)k;
 }
 
 constexpr int kXbuf = 1088;     // 1024 + 4 per 64 padding, complex entries per wave
+constexpr int kVecPerPlane = kWfSpan / 4;                 // 704 float4 per plane
+constexpr int kPref = (2 * kVecPerPlane + 255) / 256;     // 6 float4 per thread (both planes)
+
+// address of the i-th float4 of a work item's staged span (I plane first, then Q plane)
+__device__ __forceinline__ const float4 *item_vec(const float *__restrict__ iq, int item, int i) {
+    const int frame = item / kWfItemsPerFrame;
+    const int chunk = item - frame * kWfItemsPerFrame;
+    const float *base = iq + (size_t)frame * (2 * kNSamples) + chunk * (kWfRowsPerItem * 256);
+    const int plane = i >= kVecPerPlane ? 1 : 0;
+    return reinterpret_cast<const float4 *>(base + plane * kNSamples) + (i - plane * kVecPerPlane);
+}
 
 __global__ __launch_bounds__(256)
 void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ mag,
@@ -116,18 +131,39 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
     float2 *xb = s_x[wave];
     unsigned char *ob = s_out[wave];
 
+    // software pipeline over work items: the next item's samples travel HBM -> registers while the
+    // current item's rows are transformed, and are dropped into LDS at the top of the next round
+    static_assert(kPref == 6, "six named prefetch registers below");
+    float4 p0, p1, p2, p3, p4, p5;
+    p0 = p1 = p2 = p3 = p4 = p5 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool tail = tid + 256 * 5 < 2 * kVecPerPlane;       // the sixth vector exists for the first 128 threads only
+#define FT8_PREFETCH(ITEM)                                           \
+    do {                                                             \
+        p0 = *item_vec(iq, (ITEM), tid);                             \
+        p1 = *item_vec(iq, (ITEM), tid + 256);                       \
+        p2 = *item_vec(iq, (ITEM), tid + 512);                       \
+        p3 = *item_vec(iq, (ITEM), tid + 768);                       \
+        p4 = *item_vec(iq, (ITEM), tid + 1024);                      \
+        if (tail) p5 = *item_vec(iq, (ITEM), tid + 1280);            \
+    } while (0)
+    if ((int)blockIdx.x < nitems) FT8_PREFETCH((int)blockIdx.x);
+
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int frame = item / kWfItemsPerFrame;
         const int chunk = item - frame * kWfItemsPerFrame;
-        const float *fI = iq + (size_t)frame * (2 * kNSamples) + chunk * (kWfRowsPerItem * 256);
-        const float *fQ = fI + kNSamples;
 
         __syncthreads();                        // previous item's readers are done with s_in
-        for (int i = tid; i < kWfSpan / 4; i += 256) {
-            reinterpret_cast<float4 *>(s_in[0])[i] = reinterpret_cast<const float4 *>(fI)[i];
-            reinterpret_cast<float4 *>(s_in[1])[i] = reinterpret_cast<const float4 *>(fQ)[i];
+        {
+            float4 *dst = reinterpret_cast<float4 *>(&s_in[0][0]);      // s_in[1] follows s_in[0]
+            dst[tid] = p0;
+            dst[tid + 256] = p1;
+            dst[tid + 512] = p2;
+            dst[tid + 768] = p3;
+            dst[tid + 1024] = p4;
+            if (tail) dst[tid + 1280] = p5;
         }
         __syncthreads();
+        if (item + (int)gridDim.x < nitems) FT8_PREFETCH(item + (int)gridDim.x);
 
 #pragma unroll 1
         for (int rr = 0; rr < kWfRowsPerItem / 4; ++rr) {
