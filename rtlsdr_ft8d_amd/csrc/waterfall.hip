@@ -20,23 +20,46 @@
 
 namespace {
 
-struct c32 { float r, i; };
+// complex numbers as packed float2 (x = re, y = im): complex add/sub is one v_pk_add_f32, the
+// complex product two v_pk_mul_f32 + one v_pk_add_f32 (gfx950 issues packed f32 at ~1.6x the rate
+// of the scalar form).  The individual roundings are those of the R4DIF-1024 specification.
+typedef float c32 __attribute__((ext_vector_type(2)));
 
+// The half-swaps and sign flips these need are free operand modifiers of the VOP3P encoding
+// (op_sel / op_sel_hi pick the source half per result half, neg_lo / neg_hi negate it); hipcc
+// materialises them as v_mov/v_xor, so the four swizzled forms are written in assembly.
+// t + (-i)*u = (t.x + u.y, t.y - u.x)
+__device__ __forceinline__ c32 add_mul_mi(c32 t, c32 u) {
+    c32 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(t), "v"(u));
+    return r;
+}
+// t + (+i)*u = (t.x - u.y, t.y + u.x)
+__device__ __forceinline__ c32 add_mul_pi(c32 t, c32 u) {
+    c32 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(t), "v"(u));
+    return r;
+}
+// (yr*wr - yi*wi, yr*wi + yi*wr): four products, one difference, one sum -- no fused operations
 __device__ __forceinline__ c32 cmul(c32 y, float2 w) {
-    const float p1 = y.r * w.x, p2 = y.i * w.y, p3 = y.r * w.y, p4 = y.i * w.x;
-    return { p1 - p2, p3 + p4 };
+    const c32 ww = { w.x, w.y };
+    c32 p, q, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(p) : "v"(y), "v"(ww));   // (yr*wr, yi*wr)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(q) : "v"(y), "v"(ww));   // (yi*wi, yr*wi)
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(p), "v"(q));                    // (p.x - q.x, p.y + q.y)
+    return r;
 }
 
 // radix-4 DIF butterfly, forward transform: y1 = t1 - i*t3, y3 = t1 + i*t3
 __device__ __forceinline__ void bfly4(c32 &a0, c32 &a1, c32 &a2, c32 &a3) {
-    const c32 t0 = { a0.r + a2.r, a0.i + a2.i };
-    const c32 t1 = { a0.r - a2.r, a0.i - a2.i };
-    const c32 t2 = { a1.r + a3.r, a1.i + a3.i };
-    const c32 t3 = { a1.r - a3.r, a1.i - a3.i };
-    a0 = { t0.r + t2.r, t0.i + t2.i };
-    a2 = { t0.r - t2.r, t0.i - t2.i };
-    a1 = { t1.r + t3.i, t1.i - t3.r };
-    a3 = { t1.r - t3.i, t1.i + t3.r };
+    const c32 t0 = a0 + a2;
+    const c32 t1 = a0 - a2;
+    const c32 t2 = a1 + a3;
+    const c32 t3 = a1 - a3;
+    a0 = t0 + t2;
+    a2 = t0 - t2;
+    a1 = add_mul_mi(t1, t3);
+    a3 = add_mul_pi(t1, t3);
 }
 
 // two consecutive radix-4 stages on 16 register-resident points, register a = a_lo + 4*q
@@ -173,22 +196,20 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
 
             c32 x[16];
 #pragma unroll
-            for (int a = 0; a < 16; ++a) {      // rtlsdr_ft8d.c:1407-1410
-                x[a].r = sI[lane + 64 * a] * hw[a];
-                x[a].i = sQ[lane + 64 * a] * hw[a];
-            }
+            for (int a = 0; a < 16; ++a)        // rtlsdr_ft8d.c:1407-1410
+                x[a] = c32{ sI[lane + 64 * a], sQ[lane + 64 * a] } * c32{ hw[a], hw[a] };
             pass16(x, twA1, twB1);              // stages 0, 1
 #pragma unroll
-            for (int a = 0; a < 16; ++a) xb[pad_idx(lane + 64 * a)] = make_float2(x[a].r, x[a].i);
+            for (int a = 0; a < 16; ++a) xb[pad_idx(lane + 64 * a)] = make_float2(x[a].x, x[a].y);
             wave_lds_sync();
 #pragma unroll
             for (int a = 0; a < 16; ++a) {
                 const float2 v = xb[pad_idx(64 * b16 + j2 + 4 * a)];
-                x[a] = { v.x, v.y };
+                x[a] = c32{ v.x, v.y };
             }
             pass16(x, twA2, twB2);              // stages 2, 3
 #pragma unroll
-            for (int a = 0; a < 16; ++a) xb[pad_idx(64 * b16 + j2 + 4 * a)] = make_float2(x[a].r, x[a].i);
+            for (int a = 0; a < 16; ++a) xb[pad_idx(64 * b16 + j2 + 4 * a)] = make_float2(x[a].x, x[a].y);
             wave_lds_sync();
 
             // stage 4 (L = 4, no twiddles): butterfly c = lane + 64*i holds bins k0+i (y0) and 256+k0+i (y1)
@@ -199,12 +220,11 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
                 const float4 *src = reinterpret_cast<const float4 *>(xb + pad_idx(4 * c));
                 const float4 v01 = src[0], v23 = src[1];
                 const c32 a0 = { v01.x, v01.y }, a1 = { v01.z, v01.w }, a2 = { v23.x, v23.y }, a3 = { v23.z, v23.w };
-                const c32 t0 = { a0.r + a2.r, a0.i + a2.i };
-                const c32 t1 = { a0.r - a2.r, a0.i - a2.i };
-                const c32 t2 = { a1.r + a3.r, a1.i + a3.i };
-                const c32 t3 = { a1.r - a3.r, a1.i - a3.i };
-                q0[i] = quantise(t0.r + t2.r, t0.i + t2.i, s_thr);
-                q1[i] = quantise(t1.r + t3.i, t1.i - t3.r, s_thr);
+                const c32 t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = a1 - a3;
+                const c32 y0 = t0 + t2;
+                const c32 y1 = add_mul_mi(t1, t3);
+                q0[i] = quantise(y0.x, y0.y, s_thr);
+                q1[i] = quantise(y1.x, y1.y, s_thr);
             }
             // bins k0..k0+3 -> [freq_sub = k&1][pos = k>>1]  (rtlsdr_ft8d.c:1420-1428)
             const int k0 = 64 * (lane & 3) + 16 * ((lane >> 2) & 3) + 4 * (lane >> 4);
