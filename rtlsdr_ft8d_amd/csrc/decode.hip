@@ -89,10 +89,9 @@ __device__ __forceinline__ f2 tanh_pair(f2 x) {
     const f2 a = x * (945.0f + x2 * (105.0f + x2));
     const f2 b = 945.0f + x2 * (420.0f + x2 * 15.0f);
     f2 r = FAST ? div_pair_fast(a, b) : div_pair_ieee(a, b);
-    r.x = (x.x > 4.97f) ? 1.0f : r.x;
-    r.x = (x.x < -4.97f) ? -1.0f : r.x;
-    r.y = (x.y > 4.97f) ? 1.0f : r.y;
-    r.y = (x.y < -4.97f) ? -1.0f : r.y;
+    // "x < -4.97 -> -1; x > 4.97 -> +1" == "|x| > 4.97 -> copysign(1, x)" (NaN takes neither branch)
+    r.x = (__builtin_fabsf(x.x) > 4.97f) ? __builtin_copysignf(1.0f, x.x) : r.x;
+    r.y = (__builtin_fabsf(x.y) > 4.97f) ? __builtin_copysignf(1.0f, x.y) : r.y;
     return r;
 }
 
@@ -284,9 +283,9 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
             const float t0 = (cw[r] + tov[3 * r + 1]) + tov[3 * r + 2];
             const float t1 = u + tov[3 * r + 2];
             const float t2 = u + tov[3 * r + 1];
-            x[3 * r + 0] = -t0 / 2;
-            x[3 * r + 1] = -t1 / 2;
-            x[3 * r + 2] = -t2 / 2;
+            x[3 * r + 0] = t0 * -0.5f;          // == -t0 / 2 bit for bit (scaling by a power of two)
+            x[3 * r + 1] = t1 * -0.5f;
+            x[3 * r + 2] = t2 * -0.5f;
         }
         x[9] = 0.0f;
 #pragma unroll
