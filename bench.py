@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 
 BYTES_PER_FRAME = 384000 + 1404          # IQ in + 50 spot records and the count out
 HBM_PEAK_GBPS = 8000.0                   # MI355X_MICROARCH.md: 8.0 TB/s spec
+FRAMES_DEFAULT = 4096                    # the PMC traffic figures in profiles/ were collected at this batch size
 
 
 def main():
@@ -36,6 +37,8 @@ def main():
     ap.add_argument("--max-candidates", type=int, default=120)
     ap.add_argument("--cpu-frames", type=int, default=512, help="frames timed on the host CPU (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL and run the spot all-gather even with one rank (exercises the N>1 code path on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -50,9 +53,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B = args.frames
     total = B * world
@@ -73,11 +79,11 @@ def main():
 
     def step():
         dec.decode_batch_dev(iq, B, spots, nres)
-        if world > 1:        # the spot list of the whole job on every rank: one RCCL all-gather each
+        if use_dist:         # the spot list of the whole job on every rank: one RCCL all-gather each
             workload.gather_spots(spots, nres, world)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -95,7 +101,7 @@ def main():
     dec.enable_timing(False)
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
@@ -140,7 +146,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(iq, spots, nres, min(args.cpu_frames, B), args.max_candidates)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     dec.close()
@@ -153,7 +159,8 @@ def _pmc_traffic(kernel):
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(p) as f:
-            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+            e = json.load(f).get(kernel, {})
+        return e.get("hbm_bytes_per_launch") if e.get("frames_per_launch") == FRAMES_DEFAULT else None
     except (OSError, ValueError):
         return None
 

@@ -24,10 +24,10 @@
 //     expansion is v_div_scale x2, v_rcp, fma x2, mul, fma x3 (v_div_fmas), v_div_fixup.  When
 //     v_div_scale does not rescale (|numerator| >= 2^-103, moderate denominator, quotient normal)
 //     and no special value is involved, scale and fixup are the identity and the quotient is the
-//     plain rcp/fma chain.  Denominators here lie in [60, 3e4]; a wave-uniform guard checks that
-//     every numerator driver is 0 or >= 2^-100 in magnitude and finite, and only then takes the
-//     packed rcp/fma chain (bitwise the same quotient, except that a zero quotient may carry the
-//     other sign, which no later operation can observe); otherwise the compiler's division is used.
+//     plain rcp/fma chain.  Denominators here are moderate; a wave-uniform guard (see guard_key)
+//     proves that every numerator is 0 or far above the rescaling threshold, and only then takes
+//     the packed rcp/fma chain (bitwise the same quotient, except that a zero quotient may carry
+//     the other sign, which no later operation can observe); otherwise the compiler's division.
 //   * every other float expression is written in the reference's operation order and compiled
 //     with -ffp-contract=off (fused operations appear only inside the division chain above).
 #include "ft8gpu_internal.h"
@@ -104,13 +104,22 @@ __device__ __forceinline__ f2 atanh_pair(f2 x) {
     return FAST ? div_pair_fast(a, b) : div_pair_ieee(a, b);
 }
 
-// Guard key of a value that drives a fast division: (bits << 1) - 1 as unsigned.  Zero maps to
-// 0xFFFFFFFF, every other value to twice its magnitude bits minus one, so "the minimum key over all
-// drivers >= key(2^-100)" says: each driver is zero or at least 2^-100 in magnitude.  Large, infinite
-// and NaN drivers need no guard: |x| > 4.97 is overridden by fast_tanh's clamps in either path, the
-// row products are bounded by 1.0072^6, and NaN stays NaN through both division forms.
+// Guard key of a value: (bits << 1) - 1 as unsigned.  Zero maps to 0xFFFFFFFF, every other value to
+// twice its magnitude bits minus one, so "minimum key over a set >= key(T)" says: each member is
+// zero or at least T in magnitude.
+//
+// ONE guard per iteration, on the nine row products P of the lane, with T = 2^-59, covers both
+// division sites of the following work:
+//   * fast_atanh(P): numerator P*(945 - 735P^2 + 64P^4) with |P| <= 1.0072^6, so |numerator| >= 200|P|;
+//   * tov = -2*fast_atanh(P) then satisfies tov == 0 or |tov| >= 2^-59 (|atanh_r(P)| >= |P|), and the
+//     LLRs are 0 or >= 0.019 (an integer times sqrt(24/variance), variance <= 255^2).  Any sum of two
+//     or three floats that are each 0 or >= 2^-59 is 0 or >= 2^-59 * 2^-23, hence the next
+//     iteration's x = -Tnm/2 is 0 or >= 2^-83, and fast_tanh's numerator x*(945 + ...) >= 945|x|.
+// Both are far above v_div_scale's 2^-103 rescaling threshold.  Large, infinite and NaN values need
+// no guard: |x| > 4.97 is overridden by fast_tanh's clamp in either division form, the products are
+// bounded, and NaN stays NaN through both forms.  Iteration 0 starts from tov = 0.
 __device__ __forceinline__ uint32_t guard_key(float v) { return (__float_as_uint(v) << 1) - 1u; }
-constexpr uint32_t kGuardMin = ((127u - 100u) << 24) - 1u;      // guard_key(0x1p-100f)
+constexpr uint32_t kGuardMin = ((127u - 59u) << 24) - 1u;       // guard_key(0x1p-59f)
 
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -249,7 +258,7 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
     int min_errors = kLdpcM;
     uint64_t B0 = 0, B1 = 0, B2 = 0;
     int iter = 0;
-    const uint32_t guard_min = force_ieee_div ? 0xFFFFFFFFu : kGuardMin;     // debug: always take the compiler's division
+    bool fast_ok = !force_ieee_div;     // every tov is 0 or >= 2^-59 (true for the initial zeros)
     for (; iter < max_iters; ++iter) {
         // hard decision (tov = 0 in iteration 0)
         bool bit[3];
@@ -276,7 +285,6 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
         // ---- bits -> checks ------------------------------------------------------------------
         // (lanes without a third variable compute on zeros and write to the spare row)
         float x[10];
-        uint32_t gmin = 0xFFFFFFFFu;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const float u = cw[r] + tov[3 * r];
@@ -288,9 +296,7 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
             x[3 * r + 2] = t2 * -0.5f;
         }
         x[9] = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) gmin = min(gmin, guard_key(x[i]));
-        if (__all(gmin >= guard_min) && !force_ieee_div) phase_tanh<true>(x, slot, toc);
+        if (fast_ok) phase_tanh<true>(x, slot, toc);
         else phase_tanh<false>(x, slot, toc);
         wave_lds_sync();
 
@@ -316,7 +322,7 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
 
         // ---- checks -> bits ------------------------------------------------------------------
         float P[10];
-        gmin = 0xFFFFFFFFu;
+        uint32_t gmin = 0xFFFFFFFFu;
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const float v = toc[slot[i]];
@@ -324,7 +330,8 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
             gmin = min(gmin, guard_key(P[i]));
         }
         P[9] = 0.0f;
-        if (__all(gmin >= guard_min) && !force_ieee_div) phase_atanh<true>(P, tov);
+        fast_ok = __all(gmin >= kGuardMin) && !force_ieee_div;       // wave-uniform; also governs the next tanh phase
+        if (fast_ok) phase_atanh<true>(P, tov);
         else phase_atanh<false>(P, tov);
         // (the next iteration's toc stores hit only this lane's own slots; LDS is in order per wave)
     }
