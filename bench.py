@@ -66,7 +66,10 @@ def main():
     assert hi - lo == B
 
     dec = ft8.Decoder(device=local_rank, max_frames=B, min_score=10, max_candidates=args.max_candidates, ldpc_iters=20)
-    stream = torch.cuda.current_stream()
+    # one explicit torch stream carries both the decoder kernels and the RCCL gather, so that the
+    # collective is ordered after the kernels that produce the spot records
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     dec.set_stream(stream.cuda_stream)
 
     # ---- synthetic frames, generated in HBM (not timed) ----------------------------------------
@@ -145,11 +148,14 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(iq, spots, nres, min(args.cpu_frames, B), args.max_candidates)
-        print(json.dumps(out), flush=True)
+    dec.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    dec.close()
+    if rank == 0:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        print(json.dumps(out), flush=True)          # the one JSON line, after any library banners
 
 
 def _pmc_traffic(kernel):
