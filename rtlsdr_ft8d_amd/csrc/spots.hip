@@ -9,12 +9,19 @@
 
 namespace {
 
+// strcmp(a, b) == 0 on two message_t.text[25] fields in HBM: all 50 bytes are requested before the
+// first comparison, so the walk costs one memory round trip instead of one per character
 __device__ inline bool text_equal(const char *a, const char *b) {
+    char ta[25], tb[25];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) { ta[i] = a[i]; tb[i] = b[i]; }
+    bool equal = true, open = true;                 // open: no terminator seen yet
+#pragma unroll
     for (int i = 0; i < 25; ++i) {
-        if (a[i] != b[i]) return false;
-        if (a[i] == 0) return true;
+        equal = equal && (!open || ta[i] == tb[i]);
+        open = open && ta[i] != 0;
     }
-    return true;
+    return equal;
 }
 
 // strtok(text, " ") semantics: returns start index of the next token at or after *pos, or -1;

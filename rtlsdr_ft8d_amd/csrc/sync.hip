@@ -138,6 +138,11 @@ void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lis
     for (int t0i = t_begin; t0i < t_end; ++t0i) {        // scan order: time_offset ascending
         const int t0 = t0i + kT0Min;
         const int navg = sync_navg(t0);
+        // score /= navg (C int division, truncating toward zero) without an integer divide: with
+        // |score| <= 21*255 and navg <= 84 the quotient is either an integer or at least 1/84 away from
+        // one, while float(score)*fl(1/navg) is within 1e-3 of it, so adding 0.004 away from zero and
+        // truncating is exact.
+        const float rnavg = navg > 0 ? 1.0f / (float)navg : 1.0f;
 #pragma unroll 1
         for (int pass = 0; pass < 4; ++pass) {
             const int f0 = pass * 64 + lane;            // then freq_offset ascending
@@ -149,7 +154,10 @@ void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lis
             int score = sync_symbol<0, 3>(pb, sb, t0) + sync_symbol<1, 1>(pb, sb, t0) + sync_symbol<2, 4>(pb, sb, t0) +
                         sync_symbol<3, 0>(pb, sb, t0) + sync_symbol<4, 6>(pb, sb, t0) + sync_symbol<5, 5>(pb, sb, t0) +
                         sync_symbol<6, 2>(pb, sb, t0);
-            if (navg > 0) score /= navg;                // C int division, truncates toward zero
+            {
+                const float fs_ = (float)score;
+                score = (int)(fs_ * rnavg + __builtin_copysignf(0.004f, fs_));
+            }
             if (valid && score_map)
                 score_map[(size_t)frame * kScoresPerFrame + (seg * kT0Count + t0i) * kF0Count + f0] = (int16_t)score;
             const bool keep = valid && score >= min_score;
