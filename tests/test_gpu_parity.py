@@ -391,3 +391,29 @@ print('BAD', bad, 'CANDS', int(counts.sum()))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "BAD 0 CANDS" in out.stdout, out.stdout[-500:]
+
+
+def test_c_caller_self_test_and_file_replay(oracle, tmp_path):
+    """examples/ft8_replay.c: a plain C program that links libft8gpu.so and uses only the reference's
+    own three symbols (initFFTW / ft8_subsystem / freeFFTW) the way rtlsdr_ft8d.c does for -t and -r"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "ft8_replay")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu17", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "ft8_replay.c"),
+                           "-L", os.path.join(root, "rtlsdr_ft8d_amd"), "-lft8gpu",
+                           "-Wl,-rpath," + os.path.join(root, "rtlsdr_ft8d_amd"), "-lm", "-o", exe])
+    out = subprocess.run([exe, "-t"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Self-test SUCCESS!" in out.stdout and "K1JT" in out.stdout and "FN20" in out.stdout
+    # the self-test wrote selftest.iq (Q negated, :784-806); replaying it decodes again (-r path, :859-887)
+    out = subprocess.run([exe, "selftest.iq"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "Number of samples: 48000" in out.stdout and "K1JT" in out.stdout
+    # same file through the oracle's reader + decoder gives the same single spot
+    import ctypes as C
+    i2, q2 = np.zeros(48000, np.float32), np.zeros(48000, np.float32)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    assert oracle.lib().ft8o_read_raw_iq(fp(i2), fp(q2), str(tmp_path / "selftest.iq").encode()) == 48000
+    dec, n = oracle.subsystem(i2, q2)
+    assert n == 1 and f"{int(dec[0]['snr']):5d}" in out.stdout
