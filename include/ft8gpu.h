@@ -163,6 +163,16 @@ typedef struct {
 int ft8gpu_synth_frames(ft8gpu_ctx *ctx, const ft8gpu_synth_signal *signals, int nframes,
                         int nsig_per_frame, float noise_sigma, uint64_t seed, float *iq_dev);
 
+/* ---- RX front end: rtlsdr_callback(), rtlsdr_ft8d.c:76-202 ------------
+ * Whole raw RTL-SDR captures (unsigned 8-bit I,Q interleaved at 2.4 Msps) -> the 15 s / ~3200 sps
+ * float frames the decoder consumes: fs/4 mixer, CIC (N = 2, comb delay 2, effective ratio 751),
+ * 57-tap compensation FIR, scaling; every capture starts from the reset filter state.  Samples past
+ * npairs/751 are zero as after the decoder thread's tail zeroing (:243-246); normalise != 0 applies
+ * its peak normalisation to 0.5 (:248-263), after which `iq` can go straight into ft8gpu_decode_batch.
+ * raw: [ncaptures][2*npairs] bytes, npairs a multiple of 8, 16-byte aligned; iq: [ncaptures][2][48000]. */
+int ft8gpu_rx_decimate(ft8gpu_ctx *ctx, const uint8_t *raw, int ncaptures, size_t npairs,
+                       float *iq, int normalise, int flags);
+
 /* device memory helpers so that a plain C caller needs no HIP headers */
 void *ft8gpu_dev_alloc(size_t bytes);
 void  ft8gpu_dev_free(void *p);

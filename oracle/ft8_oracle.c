@@ -1190,3 +1190,105 @@ int32_t ft8o_read_c2(float *iSamples, float *qSamples, const char *filename, dou
     free(filebuffer);
     return r;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * rtlsdr_callback()  rtlsdr_ft8d.c:76-202   
+ * ---------------------------------------------------------------------------------------- */
+#define RX_DOWNSAMPLING 750            /* SAMPLING_RATE / SIGNAL_SAMPLE_RATE, rtlsdr_ft8d.h:38 */
+#define RX_FIR_TAPS 56                 /* rtlsdr_ft8d.h:40 */
+
+/* rtlsdr_ft8d.c:94-110 */
+static const float rx_zCoef[RX_FIR_TAPS + 1] = {
+    -0.0025719973,  0.0010118403,  0.0009110571, -0.0034940765,
+     0.0069713409, -0.0114242790,  0.0167023466, -0.0223683056,
+     0.0276808966, -0.0316243672,  0.0329894230, -0.0305042011,
+     0.0230074504, -0.0096499429, -0.0098950502,  0.0352349632,
+    -0.0650990428,  0.0972406918, -0.1284211497,  0.1544893973,
+    -0.1705667465,  0.1713383321, -0.1514501610,  0.1060148823,
+    -0.0312560926, -0.0745846391,  0.2096088743, -0.3638689868,
+     0.5000000000,
+    -0.3638689868,  0.2096088743, -0.0745846391, -0.0312560926,
+     0.1060148823, -0.1514501610,  0.1713383321, -0.1705667465,
+     0.1544893973, -0.1284211497,  0.0972406918, -0.0650990428,
+     0.0352349632, -0.0098950502, -0.0096499429,  0.0230074504,
+    -0.0305042011,  0.0329894230, -0.0316243672,  0.0276808966,
+    -0.0223683056,  0.0167023466, -0.0114242790,  0.0069713409,
+    -0.0034940765,  0.0009110571,  0.0010118403, -0.0025719973
+};
+
+void ft8o_rx_reset(ft8o_rx_state_t *st) { memset(st, 0, sizeof *st); }
+
+void ft8o_rx_callback(ft8o_rx_state_t *st, unsigned char *samples, uint32_t samples_count,
+                      float *iSamples, float *qSamples, uint32_t *iq_index) {
+    int8_t *sigIn = (int8_t *)samples;
+    int8_t tmp;
+    /* :129-140 economic mixer @ fs/4 (int8 stores wrap: -(-128) stays -128) */
+    for (uint32_t i = 0; i < samples_count; i += 8) {
+        sigIn[i    ] ^= 0x80;
+        sigIn[i + 1] ^= 0x80;
+        tmp          = (sigIn[i + 3] ^ 0x80);
+        sigIn[i + 3] = (sigIn[i + 2] ^ 0x80);
+        sigIn[i + 2] = -tmp;
+        sigIn[i + 4] = -(sigIn[i + 4] ^ 0x80);
+        sigIn[i + 5] = -(sigIn[i + 5] ^ 0x80);
+        tmp          = (sigIn[i + 6] ^ 0x80);
+        sigIn[i + 6] = (sigIn[i + 7] ^ 0x80);
+        sigIn[i + 7] = -tmp;
+    }
+    /* :148-201 CIC decimator (N = 2), compensation FIR, scaling.  Integrators use wrapping 32-bit
+     * arithmetic (signed overflow wraps on every target the reference runs on; made explicit here). */
+    for (int32_t i = 0; i < (int32_t)(samples_count / 2); i++) {
+        st->Ix1 = (int32_t)((uint32_t)st->Ix1 + (uint32_t)(int32_t)sigIn[i * 2]);
+        st->Qx1 = (int32_t)((uint32_t)st->Qx1 + (uint32_t)(int32_t)sigIn[i * 2 + 1]);
+        st->Ix2 = (int32_t)((uint32_t)st->Ix2 + (uint32_t)st->Ix1);
+        st->Qx2 = (int32_t)((uint32_t)st->Qx2 + (uint32_t)st->Qx1);
+
+        st->decimationIndex++;
+        if (st->decimationIndex <= RX_DOWNSAMPLING) continue;        /* :157: effective ratio 751 */
+        st->decimationIndex = 0;
+
+        st->Iy1 = (int32_t)((uint32_t)st->Ix2 - (uint32_t)st->It1z);  st->It1z = st->It1y;  st->It1y = st->Ix2;
+        st->Qy1 = (int32_t)((uint32_t)st->Qx2 - (uint32_t)st->Qt1z);  st->Qt1z = st->Qt1y;  st->Qt1y = st->Qx2;
+        st->Iy2 = (int32_t)((uint32_t)st->Iy1 - (uint32_t)st->It2z);  st->It2z = st->It2y;  st->It2y = st->Iy1;
+        st->Qy2 = (int32_t)((uint32_t)st->Qy1 - (uint32_t)st->Qt2z);  st->Qt2z = st->Qt2y;  st->Qt2y = st->Qy1;
+
+        float Isum = 0.0, Qsum = 0.0;
+        for (uint32_t j = 0; j < RX_FIR_TAPS; j++) {
+            Isum += st->firI[j] * rx_zCoef[j];
+            Qsum += st->firQ[j] * rx_zCoef[j];
+            if (j < RX_FIR_TAPS - 1) {
+                st->firI[j] = st->firI[j + 1];
+                st->firQ[j] = st->firQ[j + 1];
+            }
+        }
+        st->firI[RX_FIR_TAPS - 1] = (float)st->Iy2;
+        st->firQ[RX_FIR_TAPS - 1] = (float)st->Qy2;
+        Isum += st->firI[RX_FIR_TAPS - 1] * rx_zCoef[RX_FIR_TAPS];
+        Qsum += st->firQ[RX_FIR_TAPS - 1] * rx_zCoef[RX_FIR_TAPS];
+
+        if (*iq_index < (uint32_t)FT8O_NSAMPLES) {                    /* :196 */
+            iSamples[*iq_index] = Isum / (32768.0 * RX_DOWNSAMPLING);
+            qSamples[*iq_index] = Qsum / (32768.0 * RX_DOWNSAMPLING);
+            (*iq_index)++;
+        }
+    }
+}
+
+void ft8o_rx_capture(const unsigned char *raw, size_t nbytes, float *iSamples, float *qSamples,
+                     uint32_t *n_out, int normalise) {
+    ft8o_rx_state_t st;
+    ft8o_rx_reset(&st);
+    uint32_t idx = 0;
+    const size_t chunk = 4 * 16384;                                   /* DEFAULT_BUF_LENGTH, rtlsdr_ft8d.h:39 */
+    unsigned char *buf = (unsigned char *)malloc(chunk);
+    for (size_t off = 0; off < nbytes; off += chunk) {
+        size_t n = nbytes - off < chunk ? nbytes - off : chunk;
+        n &= ~(size_t)7;
+        memcpy(buf, raw + off, n);
+        ft8o_rx_callback(&st, buf, (uint32_t)n, iSamples, qSamples, &idx);
+    }
+    free(buf);
+    for (uint32_t i = idx; i < (uint32_t)FT8O_NSAMPLES; i++) { iSamples[i] = 0.0; qSamples[i] = 0.0; }   /* :243-246 */
+    if (normalise) ft8o_normalise(iSamples, qSamples, FT8O_NSAMPLES);                                     /* :248-263 */
+    if (n_out) *n_out = idx;
+}

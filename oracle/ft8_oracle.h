@@ -42,6 +42,7 @@
 #define FT8_ORACLE_H
 
 #include <stdint.h>
+#include <stddef.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -162,6 +163,25 @@ void ft8o_normalise(float *iSamples, float *qSamples, int n);   /* rtlsdr_ft8d.c
 int32_t ft8o_write_raw_iq(const float *iSamples, const float *qSamples, const char *filename);
 int32_t ft8o_read_raw_iq(float *iSamples, float *qSamples, const char *filename);
 int32_t ft8o_read_c2(float *iSamples, float *qSamples, const char *filename, double *dialfreq);
+
+/* rtlsdr_callback(), rtlsdr_ft8d.c:76-202: RX front end (fs/4 mixer, CIC N=2 with the reference's
+ * effective decimation of 751, 57-tap compensation FIR).  The reference keeps the filter state in
+ * function-local statics; here it is an explicit struct so that a capture can be replayed from reset. */
+typedef struct {
+    int32_t  Ix1, Ix2, Qx1, Qx2;
+    int32_t  Iy1, It1y, It1z, Qy1, Qt1y, Qt1z;
+    int32_t  Iy2, It2y, It2z, Qy2, Qt2y, Qt2z;
+    uint32_t decimationIndex;
+    float    firI[56], firQ[56];
+} ft8o_rx_state_t;
+void ft8o_rx_reset(ft8o_rx_state_t *st);
+/* processes `samples_count` raw bytes IN PLACE (the reference rewrites the buffer, :129-140) and
+ * appends decimated samples to iSamples/qSamples while *iq_index < 48000 (:195-200) */
+void ft8o_rx_callback(ft8o_rx_state_t *st, unsigned char *samples, uint32_t samples_count,
+                      float *iSamples, float *qSamples, uint32_t *iq_index);
+/* whole capture from reset + the decoder thread's tail zeroing and optional peak normalisation (:243-263) */
+void ft8o_rx_capture(const unsigned char *raw, size_t nbytes, float *iSamples, float *qSamples,
+                     uint32_t *n_out, int normalise);
 
 #ifdef __cplusplus
 }

@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "ft8gpu_get_timings", "ft8gpu_synchronize", "ft8gpu_last_error", "ft8gpu_device_count",
     "ft8gpu_decode_batch", "ft8gpu_waterfall", "ft8gpu_find_sync", "ft8gpu_score_map",
     "ft8gpu_decode_candidates", "ft8gpu_collect_spots", "ft8gpu_pack77_std", "ft8gpu_encode",
-    "ft8gpu_synth_frames", "ft8gpu_dev_alloc", "ft8gpu_dev_free", "ft8gpu_memcpy_h2d", "ft8gpu_memcpy_d2h",
+    "ft8gpu_synth_frames", "ft8gpu_rx_decimate", "ft8gpu_dev_alloc", "ft8gpu_dev_free", "ft8gpu_memcpy_h2d", "ft8gpu_memcpy_d2h",
     "initFFTW", "freeFFTW", "ft8_subsystem", "ft8gpu_read_raw_iq", "ft8gpu_read_c2", "ft8gpu_write_raw_iq",
 ]
 
@@ -94,6 +94,7 @@ def load_library():
     L.ft8gpu_encode.argtypes = [vp, vp]
     L.ft8gpu_encode.restype = None
     L.ft8gpu_synth_frames.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, C.c_uint64, vp]
+    L.ft8gpu_rx_decimate.argtypes = [vp, vp, C.c_int, C.c_size_t, vp, C.c_int, C.c_int]
     L.ft8gpu_dev_alloc.argtypes = [C.c_size_t]
     L.ft8gpu_dev_alloc.restype = vp
     L.ft8gpu_dev_free.argtypes = [vp]
@@ -260,6 +261,17 @@ class Decoder:
 
     def waterfall_dev(self, iq_dev, nframes, mag_dev):
         _check(self.lib.ft8gpu_waterfall(self.h, _ptr(iq_dev), nframes, _ptr(mag_dev), DEVICE_PTRS))
+
+    def rx_decimate(self, raw, normalise=True):
+        """raw: uint8 [ncaptures][2*npairs] host array -> float32 [ncaptures][2][48000]"""
+        raw = np.ascontiguousarray(raw, np.uint8)
+        ncap, nbytes = raw.shape
+        iq = np.zeros((ncap, 2, NSAMPLES), np.float32)
+        _check(self.lib.ft8gpu_rx_decimate(self.h, raw.ctypes.data, ncap, nbytes // 2, iq.ctypes.data, int(normalise), HOST_PTRS))
+        return iq
+
+    def rx_decimate_dev(self, raw_dev, ncaptures, npairs, iq_dev, normalise=True):
+        _check(self.lib.ft8gpu_rx_decimate(self.h, _ptr(raw_dev), ncaptures, npairs, _ptr(iq_dev), int(normalise), DEVICE_PTRS))
 
     def synth_frames(self, signals, nframes, nsig, noise_sigma, seed, iq_dev):
         signals = np.ascontiguousarray(signals)

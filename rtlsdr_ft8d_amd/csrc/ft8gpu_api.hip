@@ -109,6 +109,10 @@ struct ft8gpu_ctx {
     int16_t *d_scores = nullptr;           // lazily allocated (diagnostic)
     ft8gpu_synth_signal *d_sigs = nullptr;
     size_t sigs_cap = 0;
+    void *d_rx_sums = nullptr, *d_rx_p2 = nullptr;     // RX front end scratch
+    uint8_t *d_rx_raw = nullptr;
+    float *d_rx_iq = nullptr;
+    size_t rx_sums_cap = 0, rx_p2_cap = 0, rx_raw_cap = 0, rx_iq_cap = 0;
 };
 
 namespace {
@@ -217,7 +221,8 @@ void ft8gpu_destroy(ft8gpu_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = { c->d_tab, c->d_iq, c->d_mag, c->d_lists, c->d_list_counts, c->d_cands, c->d_counts,
-                     c->d_status, c->d_decodes, c->d_nres, c->d_scores, c->d_sigs };
+                     c->d_status, c->d_decodes, c->d_nres, c->d_scores, c->d_sigs,
+                     c->d_rx_sums, c->d_rx_p2, c->d_rx_raw, c->d_rx_iq };
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (auto &slot : c->ev) for (auto &e : slot) if (e) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -432,6 +437,41 @@ int ft8gpu_collect_spots(ft8gpu_ctx *c, const ft8gpu_candidate *cands, const int
             HIP_TRY(launch_spots(cands + (size_t)f0 * mc, counts + f0, status + (size_t)f0 * mc, n, mc, c->params.min_score,
                                  decodes + (size_t)f0 * kMaxMessages, n_results + f0, c->stream));
         }
+    }
+    return 0;
+}
+
+static int grow(void **buf, size_t *cap, size_t need) {
+    if (need <= *cap) return 0;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr;
+    *cap = 0;
+    HIP_TRY(hipMalloc(buf, need));
+    *cap = need;
+    return 0;
+}
+
+int ft8gpu_rx_decimate(ft8gpu_ctx *c, const uint8_t *raw, int ncaptures, size_t npairs, float *iq,
+                       int normalise, int flags) {
+    CHECK_COMMON(c, ncaptures);
+    if (ncaptures == 0) return 0;
+    if (!raw || !iq) return fail("NULL array argument");
+    if (npairs % 8 != 0) return fail("npairs must be a multiple of 8 (whole 16-byte units; the reference's buffers are multiples of 8 bytes)");
+    const size_t nblocks = npairs / 751 > (size_t)kNSamples ? (size_t)kNSamples : npairs / 751;
+    HIP_TRY(hipStreamSynchronize(c->stream));              // scratch may be regrown below
+    if (grow(&c->d_rx_sums, &c->rx_sums_cap, (size_t)ncaptures * (nblocks + 1) * 16)) return -1;
+    if (grow(&c->d_rx_p2, &c->rx_p2_cap, (size_t)ncaptures * ((nblocks + 15) / 16 + 1) * 16 + (size_t)ncaptures * 376 * 4)) return -1;
+    const size_t raw_bytes = (size_t)ncaptures * npairs * 2, iq_bytes = (size_t)ncaptures * 2 * kNSamples * sizeof(float);
+    if (flags & FT8GPU_DEVICE_PTRS) {
+        if (((uintptr_t)raw & 15) != 0) return fail("raw must be 16-byte aligned");
+        HIP_TRY(launch_rx(raw, ncaptures, npairs, c->d_rx_sums, c->d_rx_p2, iq, normalise, c->stream));
+    } else {
+        if (grow((void **)&c->d_rx_raw, &c->rx_raw_cap, raw_bytes)) return -1;
+        if (grow((void **)&c->d_rx_iq, &c->rx_iq_cap, iq_bytes)) return -1;
+        HIP_TRY(hipMemcpyAsync(c->d_rx_raw, raw, raw_bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(launch_rx(c->d_rx_raw, ncaptures, npairs, c->d_rx_sums, c->d_rx_p2, c->d_rx_iq, normalise, c->stream));
+        HIP_TRY(hipMemcpyAsync(iq, c->d_rx_iq, iq_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
     }
     return 0;
 }

@@ -225,3 +225,15 @@ def unpack77(a77):
 def crc14(data, nbits):
     a = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8))
     return lib().ft8o_compute_crc(_u8(a), nbits)
+
+
+def rx_capture(raw, normalise=False):
+    """rtlsdr_callback() over a whole raw capture from reset; returns (i, q, n_out)"""
+    raw = np.ascontiguousarray(raw, np.uint8)
+    L = lib()
+    L.ft8o_rx_capture.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_int]
+    i = np.zeros(NSAMPLES, np.float32)
+    q = np.zeros(NSAMPLES, np.float32)
+    n = C.c_uint32(0)
+    L.ft8o_rx_capture(raw.ctypes.data, raw.size, i.ctypes.data, q.ctypes.data, C.byref(n), int(normalise))
+    return i, q, n.value

@@ -1,0 +1,94 @@
+"""RX front end: rtlsdr_callback(), rtlsdr_ft8d.c:76-202.
+CPU: the oracle restatement behaves like the filter chain it describes.
+GPU: ft8gpu_rx_decimate is bit-identical to it, including int8 wrap (-(-128)), integrator wrap-around,
+block boundaries that cut the 4-pair mixer pattern, short captures and the tail zeroing."""
+import numpy as np
+import pytest
+
+
+def make_capture(seed, npairs, kind="signal"):
+    """raw unsigned 8-bit I/Q at 2.4 Msps around fs/4 (the reference tunes so that the band of
+    interest sits at +fs/4 and keeps the upper band)"""
+    rng = np.random.default_rng(seed)
+    if kind == "random":
+        return rng.integers(0, 256, 2 * npairs, dtype=np.uint8)
+    if kind == "extremes":                       # saturating ADC: bytes 0 and 255 everywhere
+        return (rng.integers(0, 2, 2 * npairs, dtype=np.uint8) * 255).astype(np.uint8)
+    if kind == "zeros":
+        return np.zeros(2 * npairs, np.uint8)
+    t = np.arange(npairs) / 2.4e6
+    x = np.zeros(npairs, np.complex128)
+    for f, a in [(600000 + 700.0, 40.0), (600000 + 1234.5, 25.0), (600000 - 300.0, 10.0)]:
+        x += a * np.exp(2j * np.pi * f * t)
+    x += rng.normal(0, 20, npairs) + 1j * rng.normal(0, 20, npairs)
+    raw = np.empty(2 * npairs, np.uint8)
+    raw[0::2] = np.clip(np.round(127.5 + x.real), 0, 255).astype(np.uint8)
+    raw[1::2] = np.clip(np.round(127.5 + x.imag), 0, 255).astype(np.uint8)
+    return raw
+
+
+def test_oracle_rx_chain_properties(oracle):
+    npairs = 751 * 4000
+    raw = make_capture(1, npairs)
+    i, q, n = oracle.rx_capture(raw)
+    assert n == 4000 and not i[n:].any() and not q[n:].any()
+    # a single tone 1000 Hz above fs/4 comes out at +1000 Hz of the ~3195.7 sps stream
+    t = np.arange(npairs) / 2.4e6
+    tone = np.empty(2 * npairs, np.uint8)
+    tone[0::2] = np.round(127.5 + 50 * np.cos(2 * np.pi * 601000.0 * t)).astype(np.uint8)
+    tone[1::2] = np.round(127.5 + 50 * np.sin(2 * np.pi * 601000.0 * t)).astype(np.uint8)
+    ti, tq, tn = oracle.rx_capture(tone)
+    x = (ti + 1j * tq)[300:tn]
+    spec = np.abs(np.fft.fft(x * np.hanning(x.size)))
+    fpk = np.fft.fftfreq(x.size, 751 / 2.4e6)[np.argmax(spec)]
+    assert abs(fpk - 1000.0) < 2.0
+    # linear, time-invariant in units of 751*4 pairs after the start-up transient: delaying the capture by
+    # 4 blocks (a multiple of the 4-pair mixer period) delays the output by 4 samples
+    i2, q2, n2 = oracle.rx_capture(np.concatenate([np.full(2 * 751 * 4, 128, np.uint8), raw])[:raw.size])
+    assert np.allclose(i2[400:3000], i[396:2996], atol=1e-6) and np.allclose(q2[400:3000], q[396:2996], atol=1e-6)
+    # chunking of the callback does not matter (state is carried): one call vs many
+    import ctypes as C
+    L = oracle.lib()
+
+    class St(C.Structure):
+        _fields_ = [("ints", C.c_int32 * 16), ("dec", C.c_uint32), ("firI", C.c_float * 56), ("firQ", C.c_float * 56)]
+    st = St()
+    L.ft8o_rx_reset.argtypes = [C.c_void_p]
+    L.ft8o_rx_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+    L.ft8o_rx_reset(C.byref(st))
+    ia, qa, idx = np.zeros(48000, np.float32), np.zeros(48000, np.float32), C.c_uint32(0)
+    buf = raw.copy()
+    for off in range(0, buf.size, 8 * 1000):
+        chunk = buf[off:off + 8 * 1000]
+        L.ft8o_rx_callback(C.byref(st), chunk.ctypes.data, chunk.size, ia.ctypes.data, qa.ctypes.data, C.byref(idx))
+    assert idx.value == n and np.array_equal(ia, i) and np.array_equal(qa, q)
+    # peak normalisation of the decoder thread
+    inorm, qnorm, _ = oracle.rx_capture(raw, normalise=True)
+    assert abs(max(np.abs(inorm).max(), np.abs(qnorm).max()) - 0.5) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,npairs", [("signal", 751 * 3000 + 8 * 37), ("random", 751 * 2000), ("extremes", 751 * 1500 + 744),
+                                         ("zeros", 751 * 100), ("signal", 8 * 50), ("random", 751 * 48000 + 8 * 1000)])
+def test_gpu_rx_bit_exact(oracle, gpu_decoder, kind, npairs):
+    npairs -= npairs % 8
+    raws = np.stack([make_capture(10 + k, npairs, kind) for k in range(2)])
+    for normalise in (False, True):
+        iq = gpu_decoder.rx_decimate(raws, normalise=normalise)
+        for k in range(raws.shape[0]):
+            i, q, n = oracle.rx_capture(raws[k], normalise=normalise)
+            assert n == min(48000, npairs // 751)
+            assert np.array_equal(iq[k, 0].view(np.uint32), i.view(np.uint32)), f"{kind} I differs"
+            assert np.array_equal(iq[k, 1].view(np.uint32), q.view(np.uint32)), f"{kind} Q differs"
+
+
+@pytest.mark.gpu
+def test_gpu_rx_feeds_decoder(oracle, gpu_decoder):
+    """raw capture -> RX front end -> decode, all on the GPU, equals the oracle doing the same"""
+    npairs = 751 * 6000
+    raw = make_capture(5, npairs)[None, :]
+    iq = gpu_decoder.rx_decimate(raw, normalise=True)
+    dec, n = gpu_decoder.decode_batch(iq)
+    i, q, _ = oracle.rx_capture(raw[0], normalise=True)
+    rdec, rn = oracle.subsystem(i, q)
+    assert n[0] == rn and dec[0].tobytes() == rdec.tobytes()
