@@ -135,14 +135,16 @@ def main():
         },
     }
     if rank == 0:
+        launches = int(stage_avg.pop("launches_per_stage", 1))
         kernels = {k: v for k, v in stage_avg.items() if k != "total_ms"}
         dom = max(kernels, key=kernels.get)
         dom_ms = kernels[dom]
         achieved = BYTES_PER_FRAME * B / (dom_ms * 1e-3) / 1e9
         out["roofline"] = {
             "bound": "hbm", "kernel": dom.replace("_ms", ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": _pmc_traffic(dom.replace("_ms", "")),
-            "kernel_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": BYTES_PER_FRAME * B,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": _pmc_traffic(dom.replace("_ms", ""), B, launches),
+            "kernel_ms": round(dom_ms, 4), "kernel_launches_per_step": launches,
+            "kernel_ms_per_launch": round(dom_ms / launches, 4), "algorithmic_bytes_per_launch": BYTES_PER_FRAME * B // launches,
             "stage_ms": {k: round(v, 4) for k, v in stage_avg.items()}, "stage_ms_runs": timed_runs,
             "pipeline_achieved_GBps": round(BYTES_PER_FRAME * B / (stage_avg["total_ms"] * 1e-3) / 1e9, 2),
         }
@@ -158,15 +160,18 @@ def main():
         print(json.dumps(out), flush=True)          # the one JSON line, after any library banners
 
 
-def _pmc_traffic(kernel):
+def _pmc_traffic(kernel, frames, launches):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
-    (profiles/pmc_traffic.json, produced by tools/pmc_summary.py); None until it has been collected
-    for this kernel and batch size."""
+    (profiles/pmc_traffic.json, FETCH_SIZE / WRITE_SIZE passes over this very command; counters were
+    collected with one launch per stage and are scaled to the frames one launch covers now); None
+    until it has been collected for this kernel and batch size."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(p) as f:
             e = json.load(f).get(kernel, {})
-        return e.get("hbm_bytes_per_launch") if e.get("frames_per_launch") == FRAMES_DEFAULT else None
+        if e.get("frames_per_launch") != FRAMES_DEFAULT or frames != FRAMES_DEFAULT:
+            return None
+        return int(e["hbm_bytes_per_launch"] / launches)
     except (OSError, ValueError):
         return None
 

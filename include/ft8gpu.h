@@ -95,12 +95,18 @@ typedef struct {
     float decode_ms;      /* LLR + LDPC BP + CRC + unpack */
     float spots_ms;       /* dedup + CQ spot fill */
     float total_ms;       /* first kernel start to last kernel end */
+    int32_t launches_per_stage; /* 1, or 2 when a large batch is processed as two overlapped halves: heap and
+                                   spots of one half then run on a side stream under the other half's decode,
+                                   and the per-stage figures are sums over both launches */
 } ft8gpu_timings;
 
 /* ---- lifecycle: replaces initFFTW()/freeFFTW(), rtlsdr_ft8d.c:314-347 ----------------------- */
 
-/* Creates a decoder context on GPU `device` with persistent buffers for up to `max_frames` frames.
- * `params` may be NULL (reference defaults 10 / 120 / 20).  Returns 0 on success. */
+/* Creates a decoder context on GPU `device` with persistent buffers for up to `max_frames` frames
+ * (larger batches are processed in chunks of max_frames).  `params` may be NULL (reference defaults
+ * 10 / 120 / 20).  Returns 0 on success.  A context owns its intermediate buffers and is meant for one
+ * host thread at a time; use one context per thread / per GPU (contexts are independent, unlike the
+ * reference's process-global FFTW state, rtlsdr_ft8d.c:57-60). */
 int  ft8gpu_create(ft8gpu_ctx **out, int device, int max_frames, const ft8gpu_params *params);
 void ft8gpu_destroy(ft8gpu_ctx *ctx);
 /* Use an existing hipStream_t (passed as void*) for all work of this context; NULL = own stream. */

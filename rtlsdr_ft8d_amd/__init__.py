@@ -36,7 +36,8 @@ class Params(C.Structure):
 
 class Timings(C.Structure):
     _fields_ = [("waterfall_ms", C.c_float), ("sync_ms", C.c_float), ("heap_ms", C.c_float),
-                ("decode_ms", C.c_float), ("spots_ms", C.c_float), ("total_ms", C.c_float)]
+                ("decode_ms", C.c_float), ("spots_ms", C.c_float), ("total_ms", C.c_float),
+                ("launches_per_stage", C.c_int32)]
 
 
 class Ft8GpuError(RuntimeError):

@@ -92,9 +92,15 @@ struct ft8gpu_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool timing = false;
-    static constexpr int kTimingSlots = 32;
-    hipEvent_t ev[kTimingSlots][6]{};      // ring of per-run stage events (no host sync while timing)
+    static constexpr int kTimingSlots = 32, kEvPerSlot = 14;
+    hipEvent_t ev[kTimingSlots][kEvPerSlot]{};   // ring of per-run stage events (no host sync while timing):
+                                                 // 0..7 on the main stream, 8..13 on the side stream
     long runs = 0;                         // pipeline runs recorded since timing was enabled
+    bool slot_overlapped[kTimingSlots]{};  // which form of the pipeline a slot recorded
+    hipStream_t side = nullptr;            // carries the serial kernels (heap, spots) of one half-batch
+                                           // while the main stream works on the other half
+    hipEvent_t dep[6]{};                   // cross-stream dependencies (no timing)
+    bool overlap = true;
 
     Ft8Tables *d_tab = nullptr;
     float *d_iq = nullptr;                 // staging for host-pointer calls
@@ -138,6 +144,12 @@ struct StageTimer {
     ft8gpu_ctx *c;
     explicit StageTimer(ft8gpu_ctx *ctx) : c(ctx) {}
     void mark(int i) { if (c->timing) (void)hipEventRecord(c->ev[c->runs % ft8gpu_ctx::kTimingSlots][i], c->stream); }
+    void mark_side(int i) { if (c->timing) (void)hipEventRecord(c->ev[c->runs % ft8gpu_ctx::kTimingSlots][8 + i], c->side); }
+    void done(bool overlapped) {
+        if (!c->timing) return;
+        c->slot_overlapped[c->runs % ft8gpu_ctx::kTimingSlots] = overlapped;
+        c->runs++;
+    }
 };
 
 float elapsed(hipEvent_t a, hipEvent_t b) {
@@ -146,8 +158,70 @@ float elapsed(hipEvent_t a, hipEvent_t b) {
     return ms;
 }
 
+// Large batches: the two serial kernels (exact heap replay, spot collection) keep only one lane per
+// frame busy, so they run on a side stream for one half of the batch while the main stream runs the
+// throughput kernels of the other half:
+//   main: waterfall(all) sync(H0) sync(H1) ...wait heap(H0)... decode(H0) ...wait heap(H1)... decode(H1) spots(H1)
+//   side:                 heap(H0)          heap(H1)                       spots(H0)
+int run_pipeline_overlapped(ft8gpu_ctx *c, const float *d_iq, int n, struct decoder_results *d_dec, int32_t *d_nres) {
+    StageTimer t(c);
+    const ft8gpu_params &p = c->params;
+    const int mc = p.max_candidates;
+    const int n0 = n / 2, n1 = n - n0;
+    const size_t lo = (size_t)n0;                                   // frame offset of the second half
+    uint8_t *mag1 = c->d_mag + lo * kMagArray;
+    uint32_t *lists1 = c->d_lists + lo * kSublistsPerFrame * kSublistCap;
+    int32_t *lc1 = c->d_list_counts + lo * kSublistsPerFrame;
+    ft8gpu_candidate *cands1 = c->d_cands + lo * mc;
+    int32_t *counts1 = c->d_counts + lo;
+    ft8gpu_decode_status *st1 = c->d_status + lo * mc;
+    hipEvent_t *E = c->dep;          // 0: sync(H0) done  1: sync(H1) done  2: heap(H0)  3: heap(H1)  4: decode(H0)  5: spots(H0)
+
+    t.mark(0);
+    HIP_TRY(launch_waterfall(d_iq, c->d_mag, c->d_tab, n, c->num_cus, c->stream));
+    t.mark(1);
+    HIP_TRY(launch_sync(c->d_mag, c->d_lists, c->d_list_counts, nullptr, n0, p.min_score, c->stream));
+    HIP_TRY(hipEventRecord(E[0], c->stream));
+    HIP_TRY(launch_sync(mag1, lists1, lc1, nullptr, n1, p.min_score, c->stream));
+    HIP_TRY(hipEventRecord(E[1], c->stream));
+    t.mark(2);
+    // side stream: heap(H0), heap(H1)
+    HIP_TRY(hipStreamWaitEvent(c->side, E[0], 0));
+    t.mark_side(0);
+    HIP_TRY(launch_heap(c->d_lists, c->d_list_counts, c->d_cands, c->d_counts, n0, mc, c->side));
+    t.mark_side(1);
+    HIP_TRY(hipEventRecord(E[2], c->side));
+    HIP_TRY(hipStreamWaitEvent(c->side, E[1], 0));
+    t.mark_side(2);
+    HIP_TRY(launch_heap(lists1, lc1, cands1, counts1, n1, mc, c->side));
+    t.mark_side(3);
+    HIP_TRY(hipEventRecord(E[3], c->side));
+    // main stream: decode(H0), decode(H1), spots(H1)
+    HIP_TRY(hipStreamWaitEvent(c->stream, E[2], 0));
+    t.mark(3);
+    HIP_TRY(launch_decode(c->d_mag, c->d_cands, c->d_counts, c->d_status, n0, mc, p.ldpc_iters, c->stream));
+    t.mark(4);
+    HIP_TRY(hipEventRecord(E[4], c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, E[3], 0));
+    HIP_TRY(launch_decode(mag1, cands1, counts1, st1, n1, mc, p.ldpc_iters, c->stream));
+    t.mark(5);
+    // side stream: spots(H0) while decode(H1) runs
+    HIP_TRY(hipStreamWaitEvent(c->side, E[4], 0));
+    t.mark_side(4);
+    HIP_TRY(launch_spots(c->d_cands, c->d_counts, c->d_status, n0, mc, p.min_score, d_dec, d_nres, c->side));
+    t.mark_side(5);
+    HIP_TRY(hipEventRecord(E[5], c->side));
+    HIP_TRY(launch_spots(cands1, counts1, st1, n1, mc, p.min_score, d_dec + lo * kMaxMessages, d_nres + lo, c->stream));
+    t.mark(6);
+    HIP_TRY(hipStreamWaitEvent(c->stream, E[5], 0));
+    t.mark(7);
+    t.done(true);
+    return 0;
+}
+
 // the pipeline on device pointers; all intermediates in the context's HBM buffers
 int run_pipeline(ft8gpu_ctx *c, const float *d_iq, int n, struct decoder_results *d_dec, int32_t *d_nres) {
+    if (c->overlap && n >= 512) return run_pipeline_overlapped(c, d_iq, n, d_dec, d_nres);
     StageTimer t(c);
     const ft8gpu_params &p = c->params;
     t.mark(0);
@@ -161,7 +235,7 @@ int run_pipeline(ft8gpu_ctx *c, const float *d_iq, int n, struct decoder_results
     t.mark(4);
     HIP_TRY(launch_spots(c->d_cands, c->d_counts, c->d_status, n, p.max_candidates, p.min_score, d_dec, d_nres, c->stream));
     t.mark(5);
-    if (c->timing) c->runs++;
+    t.done(false);
     return 0;
 }
 
@@ -177,10 +251,44 @@ int ft8gpu_device_count(void) {
     return n;
 }
 
+// everything that can fail after the context object exists; the caller destroys it on failure
+static int create_body(ft8gpu_ctx *c) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+    for (auto &slot : c->ev) for (auto &e : slot) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    for (auto &e : c->dep) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    { const char *e = getenv("FT8GPU_OVERLAP"); c->overlap = !(e && e[0] == '0'); }
+
+    Ft8Tables *h = (Ft8Tables *)malloc(sizeof(Ft8Tables));
+    if (!h) return fail("out of host memory");
+    if (build_tables(h)) { free(h); return -1; }
+    hipError_t e = hipMalloc(&c->d_tab, sizeof(Ft8Tables));
+    if (e == hipSuccess) e = hipMemcpy(c->d_tab, h, sizeof(Ft8Tables), hipMemcpyHostToDevice);
+    free(h);
+    if (e != hipSuccess) return fail("uploading the constant tables failed: %s", hipGetErrorString(e));
+    HIP_TRY(decode_tables_init(c->stream));
+
+    const size_t F = (size_t)c->max_frames;
+    HIP_TRY(hipMalloc(&c->d_mag, F * kMagArray));
+    HIP_TRY(hipMalloc(&c->d_lists, F * kSublistsPerFrame * kSublistCap * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&c->d_list_counts, F * kSublistsPerFrame * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&c->d_counts, F * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&c->d_decodes, F * kMaxMessages * sizeof(struct decoder_results)));
+    HIP_TRY(hipMalloc(&c->d_nres, F * sizeof(int32_t)));
+    if (alloc_candidate_buffers(c, c->params.max_candidates < 120 ? 120 : c->params.max_candidates)) return -1;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int ft8gpu_create(ft8gpu_ctx **out, int device, int max_frames, const ft8gpu_params *params) {
     if (!out) return fail("ft8gpu_create: out is NULL");
     *out = nullptr;
     if (max_frames < 1) return fail("ft8gpu_create: max_frames must be >= 1");
+    if (params && check_params(params)) return -1;
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail("ft8gpu_create: device %d not present (%d visible)", device, ndev);
@@ -188,30 +296,14 @@ int ft8gpu_create(ft8gpu_ctx **out, int device, int max_frames, const ft8gpu_par
     ft8gpu_ctx *c = new ft8gpu_ctx();
     c->device = device;
     c->max_frames = max_frames;
-    if (params) { if (check_params(params)) { delete c; return -1; } c->params = *params; }
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    c->own_stream = true;
-    for (auto &slot : c->ev) for (auto &e : slot) HIP_TRY(hipEventCreate(&e));
-
-    Ft8Tables *h = (Ft8Tables *)malloc(sizeof(Ft8Tables));
-    if (build_tables(h)) { free(h); ft8gpu_destroy(c); return -1; }
-    HIP_TRY(hipMalloc(&c->d_tab, sizeof(Ft8Tables)));
-    HIP_TRY(hipMemcpy(c->d_tab, h, sizeof(Ft8Tables), hipMemcpyHostToDevice));
-    free(h);
-    HIP_TRY(decode_tables_init(c->stream));
-
-    const size_t F = (size_t)max_frames;
-    HIP_TRY(hipMalloc(&c->d_mag, F * kMagArray));
-    HIP_TRY(hipMalloc(&c->d_lists, F * kSublistsPerFrame * kSublistCap * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&c->d_list_counts, F * kSublistsPerFrame * sizeof(int32_t)));
-    HIP_TRY(hipMalloc(&c->d_counts, F * sizeof(int32_t)));
-    HIP_TRY(hipMalloc(&c->d_decodes, F * kMaxMessages * sizeof(struct decoder_results)));
-    HIP_TRY(hipMalloc(&c->d_nres, F * sizeof(int32_t)));
-    if (alloc_candidate_buffers(c, c->params.max_candidates < 120 ? 120 : c->params.max_candidates)) { ft8gpu_destroy(c); return -1; }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (params) c->params = *params;
+    if (create_body(c)) {
+        char keep[sizeof g_err];
+        memcpy(keep, g_err, sizeof keep);          // ft8gpu_destroy must not clobber the reason
+        ft8gpu_destroy(c);
+        memcpy(g_err, keep, sizeof keep);
+        return -1;
+    }
     *out = c;
     return 0;
 }
@@ -224,7 +316,10 @@ void ft8gpu_destroy(ft8gpu_ctx *c) {
                      c->d_status, c->d_decodes, c->d_nres, c->d_scores, c->d_sigs,
                      c->d_rx_sums, c->d_rx_p2, c->d_rx_raw, c->d_rx_iq };
     for (void *b : bufs) if (b) (void)hipFree(b);
+    if (c->side) (void)hipStreamSynchronize(c->side);
     for (auto &slot : c->ev) for (auto &e : slot) if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->dep) if (e) (void)hipEventDestroy(e);
+    if (c->side) (void)hipStreamDestroy(c->side);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -233,6 +328,7 @@ int ft8gpu_set_stream(ft8gpu_ctx *c, void *hip_stream) {
     if (!c) return fail("ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->side));
     if (c->own_stream) { (void)hipStreamDestroy(c->stream); c->own_stream = false; }
     if (hip_stream) c->stream = (hipStream_t)hip_stream;
     else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
@@ -265,11 +361,25 @@ int ft8gpu_get_timings(ft8gpu_ctx *c, ft8gpu_timings *out, int32_t *nruns) {
     HIP_TRY(hipSetDevice(c->device));
     const int n = c->runs < ft8gpu_ctx::kTimingSlots ? (int)c->runs : ft8gpu_ctx::kTimingSlots;
     double acc[6] = { 0, 0, 0, 0, 0, 0 };
+    int launches = 1;
     for (int k = 0; k < n; k++) {
-        hipEvent_t *e = c->ev[(c->runs - 1 - k) % ft8gpu_ctx::kTimingSlots];
-        HIP_TRY(hipEventSynchronize(e[5]));
-        for (int i = 0; i < 5; i++) acc[i] += elapsed(e[i], e[i + 1]);
-        acc[5] += elapsed(e[0], e[5]);
+        const int slot = (int)((c->runs - 1 - k) % ft8gpu_ctx::kTimingSlots);
+        hipEvent_t *e = c->ev[slot];
+        if (c->slot_overlapped[slot]) {
+            HIP_TRY(hipEventSynchronize(e[7]));
+            HIP_TRY(hipEventSynchronize(e[8 + 5]));
+            acc[0] += elapsed(e[0], e[1]);                                   // waterfall
+            acc[1] += elapsed(e[1], e[2]);                                   // sync: both halves
+            acc[2] += elapsed(e[8], e[9]) + elapsed(e[10], e[11]);           // heap: both halves (side stream, overlapped)
+            acc[3] += elapsed(e[3], e[4]) + elapsed(e[4], e[5]);             // decode: both launches
+            acc[4] += elapsed(e[12], e[13]) + elapsed(e[5], e[6]);           // spots: H0 (side, overlapped) + H1
+            acc[5] += elapsed(e[0], e[7]);
+            launches = 2;
+        } else {
+            HIP_TRY(hipEventSynchronize(e[5]));
+            for (int i = 0; i < 5; i++) acc[i] += elapsed(e[i], e[i + 1]);
+            acc[5] += elapsed(e[0], e[5]);
+        }
     }
     out->waterfall_ms = (float)(acc[0] / n);
     out->sync_ms = (float)(acc[1] / n);
@@ -277,13 +387,14 @@ int ft8gpu_get_timings(ft8gpu_ctx *c, ft8gpu_timings *out, int32_t *nruns) {
     out->decode_ms = (float)(acc[3] / n);
     out->spots_ms = (float)(acc[4] / n);
     out->total_ms = (float)(acc[5] / n);
+    out->launches_per_stage = launches;
     if (nruns) *nruns = n;
     return 0;
 }
 
 int ft8gpu_synchronize(ft8gpu_ctx *c) {
     if (!c) return fail("ctx is NULL");
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));                // the main stream joins the side stream at the end of a run
     return 0;
 }
 
