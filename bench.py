@@ -169,9 +169,9 @@ def _pmc_traffic(kernel, frames, launches):
     try:
         with open(p) as f:
             e = json.load(f).get(kernel, {})
-        if e.get("frames_per_launch") != FRAMES_DEFAULT or frames != FRAMES_DEFAULT:
+        if not e or e.get("frames_per_launch") != frames // launches:
             return None
-        return int(e["hbm_bytes_per_launch"] / launches)
+        return int(e["hbm_bytes_per_launch"])
     except (OSError, ValueError):
         return None
 

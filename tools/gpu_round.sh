@@ -17,4 +17,5 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST
 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc/sq2 -o sq2 -- $CMD > gpurun_out/pmc/sq2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc/fetch -o fetch -- $CMD > gpurun_out/pmc/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc/write -o write -- $CMD > gpurun_out/pmc/write.log 2>&1
+python tools/pmc_summary.py --traffic gpurun_out/pmc_traffic.json gpurun_out/pmc/*/*_counter_collection.csv > gpurun_out/pmc_counters.json
 cat gpurun_out/prof/trace_kernel_stats.csv | cut -c1-160 | head -9

@@ -1,22 +1,41 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc counter_collection CSVs per kernel (mean per dispatch).
-usage: tools/pmc_summary.py gpurun_out/pmc/*/ *_counter_collection.csv"""
-import csv
+"""Summarise rocprofv3 --pmc counter_collection CSVs per kernel (mean per dispatch) and derive the HBM
+traffic file bench.py reads.
+
+usage: tools/pmc_summary.py [--traffic profiles/pmc_traffic.json --frames 4096] gpurun_out/pmc/*/*_counter_collection.csv
+
+HBM bytes follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE in separate passes, units
+of KB; on gfx950 FETCH_SIZE reads exactly half of a wide (16 B/lane) coalesced stream, so it is doubled for
+the kernels whose reads are such streams (waterfall, sync, rx_block) -- checked on a known byte count: the
+waterfall kernel requests 23 x 2816 x 8 B x 4096 frames = 2.12 GB per launch and the doubled counter reads
+2.12 GB.  Byte/dword gathers (decode, heap, spots) are an uncalibrated pattern: the raw counter is kept."""
+import argparse
 import collections
+import csv
 import json
-import sys
+
+KERNELS = ("ft8_decode_kernel", "ft8_waterfall_kernel", "ft8_sync_kernel", "ft8_heap_kernel", "ft8_spots_kernel",
+           "ft8_synth_kernel", "ft8_rx_block_kernel")
+WIDE = {"waterfall", "sync", "rx_block"}
+HALF_BATCH = {"sync", "heap", "decode", "spots"}      # launched once per half batch when the pipeline overlaps halves
 
 
 def short(name):
-    for k in ("ft8_decode_kernel", "ft8_waterfall_kernel", "ft8_sync_kernel", "ft8_heap_kernel", "ft8_spots_kernel", "ft8_synth_kernel"):
+    for k in KERNELS:
         if k in name:
             return k.replace("ft8_", "").replace("_kernel", "")
     return None
 
 
-def main(paths):
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("paths", nargs="+")
+    ap.add_argument("--traffic")
+    ap.add_argument("--frames", type=int, default=4096)
+    ap.add_argument("--no-overlap", action="store_true", help="counters were collected with FT8GPU_OVERLAP=0")
+    args = ap.parse_args()
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for p in paths:
+    for p in args.paths:
         with open(p) as f:
             for row in csv.DictReader(f):
                 k = short(row["Kernel_Name"])
@@ -28,7 +47,19 @@ def main(paths):
         out[k] = {c: sum(v) / len(v) for c, v in d.items()}
         out[k]["dispatches"] = max(len(v) for v in d.values())
     print(json.dumps(out, indent=1))
+    if args.traffic:
+        t = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over "
+                       "`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline`, mean per dispatch; tools/gpu_round.sh + tools/pmc_summary.py"}
+        for k, v in out.items():
+            if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v or k == "synth":
+                continue
+            f, w = v["FETCH_SIZE"] * 1024, v["WRITE_SIZE"] * 1024
+            frames = args.frames // 2 if (k in HALF_BATCH and not args.no_overlap) else args.frames
+            t[k] = {"fetch_size_kb_raw": round(v["FETCH_SIZE"], 1), "write_size_kb_raw": round(v["WRITE_SIZE"], 1),
+                    "fetch_correction": "x2 (16 B/lane coalesced stream)" if k in WIDE else "x1 (byte/dword gathers: uncalibrated pattern, raw counter)",
+                    "hbm_bytes_per_launch": int((2 * f if k in WIDE else f) + w), "frames_per_launch": frames}
+        json.dump(t, open(args.traffic, "w"), indent=1)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:])
+    main()
