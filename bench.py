@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--nsig", type=int, default=20, help="FT8 signals per frame")
     ap.add_argument("--snr", type=float, nargs=2, default=(-18.0, 0.0))
     ap.add_argument("--max-candidates", type=int, default=120)
-    ap.add_argument("--cpu-frames", type=int, default=512, help="frames timed on the host CPU (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=2048, help="frames timed on the host CPU (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the spot all-gather even with one rank (exercises the N>1 code path on one GPU)")
