@@ -175,7 +175,13 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform by construction: keep it in an SGPR
-    const long gw = (long)blockIdx.x * 4 + wave;
+    // XCD-aware block order: the dispatcher places block b on XCD b % 8 (each XCD has its own L2), so
+    // blocks are renumbered to give every XCD a contiguous range of candidates -- the 30 blocks that
+    // gather from one frame's 94 KB waterfall then share one L2 instead of pulling it into all eight.
+    // (Placement only affects cache traffic; any mapping is correct.)
+    const unsigned nb = gridDim.x, per = nb >> 3, main_blocks = per << 3;
+    const unsigned vb = blockIdx.x < main_blocks ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
+    const long gw = (long)vb * 4 + wave;
     const int frame = (int)(gw / max_candidates);
     const int ci = (int)(gw - (long)frame * max_candidates);
     if (frame >= nframes) return;

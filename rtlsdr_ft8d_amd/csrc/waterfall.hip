@@ -107,6 +107,19 @@ constexpr int kXbuf = 1088;     // 1024 + 4 per 64 padding, complex entries per 
 constexpr int kVecPerPlane = kWfSpan / 4;                 // 704 float4 per plane
 constexpr int kPref = (2 * kVecPerPlane + 255) / 256;     // 6 float4 per thread (both planes)
 
+// XCD-aware work order.  The dispatcher places workgroup w on XCD w % 8 (each XCD has its own L2).
+// Consecutive chunks of a frame share 768 of their 2816 samples, so every XCD is given whole frames
+// (frame f belongs to XCD f % 8) and its workgroups walk that XCD's chunks in order, which keeps the
+// overlap re-read inside one L2.  step = k-th item of this workgroup; returns the flat item index
+// frame * 23 + chunk, or -1 when the XCD has no more work.  (Placement affects cache traffic only.)
+__device__ __forceinline__ int xcd_item(int step, int nframes) {
+    const int xcd = blockIdx.x & 7, lw = blockIdx.x >> 3, wgs = gridDim.x >> 3;
+    const int j = lw + wgs * step;                            // position in this XCD's chunk list
+    const int fx = j / kWfItemsPerFrame, chunk = j - fx * kWfItemsPerFrame;
+    const int frame = fx * 8 + xcd;
+    return frame < nframes ? frame * kWfItemsPerFrame + chunk : -1;
+}
+
 // address of the i-th float4 of a work item's staged span (I plane first, then Q plane)
 __device__ __forceinline__ const float4 *item_vec(const float *__restrict__ iq, int item, int i) {
     const int frame = item / kWfItemsPerFrame;
@@ -118,7 +131,7 @@ __device__ __forceinline__ const float4 *item_vec(const float *__restrict__ iq, 
 
 __global__ __launch_bounds__(256)
 void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ mag,
-                          const Ft8Tables *__restrict__ tab, int nitems) {
+                          const Ft8Tables *__restrict__ tab, int nitems, int nframes, int xcd_order) {
     __shared__ __attribute__((aligned(16))) float s_in[2][kWfSpan];          // staged I and Q
     __shared__ __attribute__((aligned(16))) float2 s_x[4][kXbuf];            // per-wave exchange
     __shared__ __attribute__((aligned(16))) float s_thr[260];
@@ -169,9 +182,12 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
         p4 = *item_vec(iq, (ITEM), tid + 1024);                      \
         if (tail) p5 = *item_vec(iq, (ITEM), tid + 1280);            \
     } while (0)
-    if ((int)blockIdx.x < nitems) FT8_PREFETCH((int)blockIdx.x);
+    // item sequence of this workgroup: XCD-aware when the grid is a multiple of 8 workgroups, else strided
+    int step = 0;
+    int item = xcd_order ? xcd_item(0, nframes) : ((int)blockIdx.x < nitems ? (int)blockIdx.x : -1);
+    if (item >= 0) FT8_PREFETCH(item);
 
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    while (item >= 0) {
         const int frame = item / kWfItemsPerFrame;
         const int chunk = item - frame * kWfItemsPerFrame;
 
@@ -186,7 +202,11 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
             if (tail) dst[tid + 1280] = p5;
         }
         __syncthreads();
-        if (item + (int)gridDim.x < nitems) FT8_PREFETCH(item + (int)gridDim.x);
+        ++step;
+        int next_item;
+        if (xcd_order) next_item = xcd_item(step, nframes);
+        else { next_item = item + (int)gridDim.x; if (next_item >= nitems) next_item = -1; }
+        if (next_item >= 0) FT8_PREFETCH(next_item);
 
 #pragma unroll 1
         for (int rr = 0; rr < kWfRowsPerItem / 4; ++rr) {
@@ -239,6 +259,7 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
             dst[lane] = reinterpret_cast<const uint2 *>(ob)[lane];
             wave_lds_sync();                    // ob / xb are rewritten by the next row
         }
+        item = next_item;
     }
 }
 
@@ -250,6 +271,8 @@ hipError_t launch_waterfall(const float *iq, uint8_t *mag, const Ft8Tables *tab,
     int grid = num_cus * 2;                     // 2 workgroups per CU (LDS-limited), persistent
     if (grid > nitems) grid = nitems;
     if (grid < 1) return hipSuccess;
-    hipLaunchKernelGGL(ft8_waterfall_kernel, dim3(grid), dim3(256), 0, s, iq, mag, tab, nitems);
+    // XCD-aware order needs whole groups of 8 workgroups and enough frames to give every XCD work
+    const int xcd_order = (grid % 8 == 0 && nframes >= 64) ? 1 : 0;
+    hipLaunchKernelGGL(ft8_waterfall_kernel, dim3(grid), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xcd_order);
     return hipGetLastError();
 }
