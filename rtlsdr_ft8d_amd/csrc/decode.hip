@@ -376,8 +376,14 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
                 if (rc < 0) for (int i = 0; i < 25; ++i) st.text[i] = 0;
             }
         }
-        status[(size_t)frame * max_candidates + ci] = st;
+        // stage the 48-byte record in LDS (the LLR area is free now) ...
+        *reinterpret_cast<ft8gpu_decode_status *>(llr) = st;
     }
+    // ... and store it as one contiguous 12-dword burst instead of lane 0's scattered narrow stores
+    wave_lds_sync();
+    static_assert(sizeof(ft8gpu_decode_status) == 48, "record is 12 dwords");
+    if (lane < 12)
+        reinterpret_cast<uint32_t *>(status + (size_t)frame * max_candidates + ci)[lane] = reinterpret_cast<const uint32_t *>(llr)[lane];
 }
 
 }  // namespace
