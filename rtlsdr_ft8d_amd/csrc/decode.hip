@@ -127,13 +127,19 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// sum over the 64 lanes with DPP adds (no LDS crossbar round trips); the total comes back uniform
 __device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror: every lane holds its row's sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);   // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
-// ftx_compute_crc(a91 with bits 77.. cleared, 82 bits): CRC-14, polynomial 0x2757
+// ftx_compute_crc(a91 with bits 77.. cleared, 82 bits): CRC-14, polynomial 0x2757.  Bit-serial
+// restatement (only the first 77 bits can be set; five zero bits follow).
 __device__ inline uint32_t crc14_82(const uint8_t *msg) {
     uint32_t rem = 0;
     int idx_byte = 0;
@@ -170,7 +176,8 @@ __device__ __forceinline__ void phase_atanh(const float (&P)[10], float (&tov)[9
 __global__ __launch_bounds__(256)
 void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *__restrict__ cands,
                        const int32_t *__restrict__ counts, ft8gpu_decode_status *__restrict__ status,
-                       int nframes, int max_candidates, int max_iters, int force_ieee_div) {
+                       int nframes, int max_candidates, int max_iters, int force_ieee_div,
+                       unsigned blocks_per_frame, unsigned bpf_magic) {
     __shared__ __attribute__((aligned(16))) float s_mem[4][kWaveLds];
 
     const int lane = threadIdx.x & 63;
@@ -181,10 +188,11 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
     // (Placement only affects cache traffic; any mapping is correct.)
     const unsigned nb = gridDim.x, per = nb >> 3, main_blocks = per << 3;
     const unsigned vb = blockIdx.x < main_blocks ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
-    const long gw = (long)vb * 4 + wave;
-    const int frame = (int)(gw / max_candidates);
-    const int ci = (int)(gw - (long)frame * max_candidates);
-    if (frame >= nframes) return;
+    // vb = frame * blocks_per_frame + group; bpf_magic = floor(2^32 / blocks_per_frame) + 1 makes the
+    // quotient one multiply-high (exact for vb * blocks_per_frame < 2^32, checked at launch)
+    const int frame = (int)__umulhi(vb, bpf_magic);
+    const int ci = (int)(vb - (unsigned)frame * blocks_per_frame) * 4 + wave;
+    if (frame >= nframes || ci >= max_candidates) return;
     if (ci >= counts[frame]) return;                        // wave-uniform
 
     float *toc = s_mem[wave];
@@ -214,8 +222,6 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
         llr[3 * k + 1] = (float)l1;
         llr[3 * k + 2] = (float)l2;
     }
-    // check-row tile: unused 7th / 8th slots must read 1.0f
-    for (int i = lane; i < kTocFloats; i += 64) toc[i] = 1.0f;
     wave_lds_sync();
 
     // ---- ftx_normalize_logl ----------------------------------------------------------------
@@ -255,6 +261,17 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
         rowidx[rr] = rvalid[rr] ? lane + 64 * rr : kRows - 1;
 #pragma unroll
         for (int w = 0; w < 3; ++w) rmask[rr][w] = d_tab.rowmask[rr][lane][w];
+    }
+
+    // check-row tile: the 7th slot of a 6-member row is never written by an edge and must read 1.0f
+    // from the first iteration on (afterwards the row owner rewrites it every iteration); the spare
+    // row only needs finite content
+    {
+        float *hiz0 = reinterpret_cast<float *>(planeHI + rowidx[0]) + 2, *hiz1 = reinterpret_cast<float *>(planeHI + rowidx[1]) + 2;
+        *hiz0 = 1.0f;
+        *hiz1 = 1.0f;
+        if (lane < 8) toc[slot_index(kRows - 1, lane)] = 1.0f;
+        wave_lds_sync();
     }
 
     // ---- bp_decode ---------------------------------------------------------------------------
@@ -424,9 +441,11 @@ hipError_t launch_decode(const uint8_t *mag, const ft8gpu_candidate *cands, cons
     // path the guard falls back to); used by the parity tests to cover that path
     static const int force_ieee_div = [] { const char *e = getenv("FT8GPU_FORCE_IEEE_DIV"); return (e && e[0] == '1') ? 1 : 0; }();
     if (nframes < 1) return hipSuccess;
-    const long nwaves = (long)nframes * max_candidates;
-    const unsigned grid = (unsigned)((nwaves + 3) / 4);
-    hipLaunchKernelGGL(ft8_decode_kernel, dim3(grid), dim3(256), 0, s,
-                       mag, cands, counts, status, nframes, max_candidates, ldpc_iters, force_ieee_div);
+    const unsigned bpf = (unsigned)(max_candidates + 3) / 4;                  // blocks (of 4 candidate waves) per frame
+    const unsigned long long nblocks = (unsigned long long)nframes * bpf;
+    if (nblocks * bpf >= (1ull << 32)) return hipErrorInvalidValue;           // keeps the multiply-high division exact
+    const unsigned magic = (unsigned)((1ull << 32) / bpf) + 1u;
+    hipLaunchKernelGGL(ft8_decode_kernel, dim3((unsigned)nblocks), dim3(256), 0, s,
+                       mag, cands, counts, status, nframes, max_candidates, ldpc_iters, force_ieee_div, bpf, magic);
     return hipGetLastError();
 }

@@ -417,3 +417,19 @@ def test_c_caller_self_test_and_file_replay(oracle, tmp_path):
     assert oracle.lib().ft8o_read_raw_iq(fp(i2), fp(q2), str(tmp_path / "selftest.iq").encode()) == 48000
     dec, n = oracle.subsystem(i2, q2)
     assert n == 1 and f"{int(dec[0]['snr']):5d}" in out.stdout
+
+
+@pytest.mark.parametrize("cap,min_score,iters", [(33, 10, 20), (7, 12, 5), (250, 8, 20)])
+def test_end_to_end_other_parameters(oracle, gpu_decoder, frames, cap, min_score, iters):
+    """run-time forms of K_MAX_CANDIDATES / K_MIN_SCORE / K_LDPC_ITERS (rtlsdr_ft8d.h:43-45), including
+    caps that are not a multiple of the 4 candidate waves of a decode workgroup"""
+    gpu_decoder.set_params(min_score=min_score, max_candidates=cap, ldpc_iters=iters)
+    try:
+        iq = np.stack([f for _, f in frames[:7]])
+        dec, n = gpu_decoder.decode_batch(iq)
+        p = oracle.default_params(min_score, cap, iters)
+        for k in range(iq.shape[0]):
+            rdec, rn = oracle.subsystem(iq[k, 0], iq[k, 1], p)
+            assert n[k] == rn and dec[k].tobytes() == rdec.tobytes(), frames[k][0]
+    finally:
+        gpu_decoder.set_params(min_score=10, max_candidates=120, ldpc_iters=20)
