@@ -143,6 +143,7 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "kernel": dom.replace("_ms", ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": _pmc_traffic(dom.replace("_ms", ""), B, launches),
+            "valu_busy_frac_pmc": _pmc_valu_busy(dom.replace("_ms", "")),
             "kernel_ms": round(dom_ms, 4), "kernel_launches_per_step": launches,
             "kernel_ms_per_launch": round(dom_ms / launches, 4), "algorithmic_bytes_per_launch": BYTES_PER_FRAME * B // launches,
             "stage_ms": {k: round(v, 4) for k, v in stage_avg.items()}, "stage_ms_runs": timed_runs,
@@ -158,6 +159,16 @@ def main():
         sys.stdout.flush()
         sys.stderr.flush()
         print(json.dumps(out), flush=True)          # the one JSON line, after any library banners
+
+
+def _pmc_valu_busy(kernel):
+    """fraction of SIMD cycles with a VALU instruction in flight for the dominant kernel, from the committed
+    PMC summary (the path is VALU-bound, so this is the roof that actually binds)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get(kernel, {}).get("valu_busy_frac")
+    except (OSError, ValueError):
+        return None
 
 
 def _pmc_traffic(kernel, frames, launches):

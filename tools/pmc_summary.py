@@ -58,6 +58,9 @@ def main():
             t[k] = {"fetch_size_kb_raw": round(v["FETCH_SIZE"], 1), "write_size_kb_raw": round(v["WRITE_SIZE"], 1),
                     "fetch_correction": "x2 (16 B/lane coalesced stream)" if k in WIDE else "x1 (byte/dword gathers: uncalibrated pattern, raw counter)",
                     "hbm_bytes_per_launch": int((2 * f if k in WIDE else f) + w), "frames_per_launch": frames}
+            if "SQ_ACTIVE_INST_VALU" in v and "GRBM_GUI_ACTIVE" in v:
+                # SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+                t[k]["valu_busy_frac"] = round(v["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * v["GRBM_GUI_ACTIVE"] / 8), 3)
         json.dump(t, open(args.traffic, "w"), indent=1)
 
 
