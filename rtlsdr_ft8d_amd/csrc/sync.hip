@@ -3,8 +3,8 @@
 //
 // Two kernels:
 //   ft8_sync_kernel  one workgroup per (frame, time_sub, freq_sub): stages that 92x256-byte slice
-//                    of the waterfall in LDS, derives a 5-point-stencil int16 map from it (the
-//                    score of 12 of the 21 sync symbols is then a single LDS read), scores all
+//                    of the waterfall in LDS, derives a 5-point-stencil int16 map from it (every
+//                    sync symbol is then one map read, 9 of the 21 with a two-byte correction), scores all
 //                    36 x 249 (time_offset, freq_offset) positions with the integer Costas
 //                    neighbour-contrast score, and compacts the positions with score >= min_score,
 //                    in the reference's scan order, with __ballot/popcount prefix sums (no atomics,
@@ -31,36 +31,33 @@ constexpr int kGuardS = 10 * kSPitch * 2;
 constexpr int kSyncLds = kOffS + kNumBlocks * kSPitch * 2 + kGuardS;   // 79104 bytes: two workgroups per CU
 
 // Contribution of one sync symbol (Costas index K, tone column C) of ft8_sync_score() at absolute
-// block b = t0 + 36 m + K (wave-uniform) and bin column f0 + C.  For K in {1,2,4,5} all four
-// neighbour terms exist away from the first/last block, and the whole contribution is one read of
-// the 5-point stencil map
-//   S5[b][f] = (p-p[f-1]) + (p-p[f+1]) + [b>0](p-p[b-1][f]) + [b<91](p-p[b+1][f]),
-// whose boundary rows already omit the missing time neighbour exactly as the reference does.
-// K = 0 has no earlier sync symbol, K = 6 no later one, and K = 3 (tone 0) no lower bin.
-// pb / sb point at (row t0, column f0) of P / S5; everything that depends on b is a scalar weight.
+// block b = t0 + 36 m + K (wave-uniform) and bin column f = f0 + C.  The 5-point stencil map
+//   S5[b][f] = [f>0](p-p[f-1]) + (p-p[f+1]) + [b>0](p-p[b-1][f]) + [b<91](p-p[b+1][f])
+// already omits a missing time neighbour at the first/last block exactly as the reference does, and
+// for K in {1,2,4,5} it IS the symbol's contribution.  The other three symbols lack one term:
+//   K = 0 (first of a Costas block) has no look-back:    S5 - [b>0](p-p[b-1][f])
+//   K = 6 (last of a Costas block) has no look-ahead:     S5 - [b<91](p-p[b+1][f])
+//   K = 3 (tone 0) has no lower bin:                      S5 - [f>0](p-p[f-1])
+// so every symbol is one S5 read, three of them with a two-byte correction.  pb / sb point at
+// (row t0, column f0) of P / S5; everything that depends on b is a wave-uniform 0/1 weight.
 template <int K, int C>
-__device__ __forceinline__ int sync_symbol(const uint8_t *pb, const int16_t *sb, int t0) {
+__device__ __forceinline__ int sync_symbol(const uint8_t *pb, const int16_t *sb, int t0, bool f_gt0) {
     int acc = 0;
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         const int rel = 36 * m + K;                                      // compile-time row offset from t0
         const int b = t0 + rel;                                          // wave-uniform
         const int w = (b >= 0 && b < kNumBlocks) ? 1 : 0;
-        if (K == 1 || K == 2 || K == 4 || K == 5) {
-            acc += w * (int)sb[rel * kSPitch + C];
-        } else {
-            const int c = pb[rel * kPitch + C];
-            int t = c - pb[rel * kPitch + C + 1];
-            if (C > 0) t += c - pb[rel * kPitch + C - 1];
-            acc += w * t;
-            if (K > 0) {
-                const int wm = (w && b > 0) ? 1 : 0;
-                acc += wm * (c - (int)pb[(rel - 1) * kPitch + C]);
-            }
-            if (K < 6) {
-                const int wp = (w && b + 1 < kNumBlocks) ? 1 : 0;
-                acc += wp * (c - (int)pb[(rel + 1) * kPitch + C]);
-            }
+        acc += w * (int)sb[rel * kSPitch + C];
+        if (K == 0) {
+            const int wm = (w && b > 0) ? 1 : 0;
+            acc -= wm * ((int)pb[rel * kPitch + C] - (int)pb[(rel - 1) * kPitch + C]);
+        } else if (K == 6) {
+            const int wp = (w && b + 1 < kNumBlocks) ? 1 : 0;
+            acc -= wp * ((int)pb[rel * kPitch + C] - (int)pb[(rel + 1) * kPitch + C]);
+        } else if (K == 3) {
+            const int d = (int)pb[rel * kPitch + C] - (int)pb[rel * kPitch + C - 1];
+            acc -= w * (f_gt0 ? d : 0);                                  // C == 0: the lower bin exists for f0 > 0 only
         }
     }
     return acc;
@@ -101,15 +98,15 @@ void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lis
             *reinterpret_cast<const uint4 *>(src + (size_t)row * kBlockStride + col);
     }
     __syncthreads();
-    // 5-point stencil map, four cells per thread from dword reads; columns 0 and 255 are never
-    // addressed by a tone that has both bin neighbours and are left 0
+    // 5-point stencil map, four cells per thread from dword reads; column 0 has no lower bin,
+    // column 255 is never addressed (f0 + tone <= 254) and is left 0
     for (int i = tid; i < kNumBlocks * 64; i += 64 * kSyncWaves) {
         const int row = i >> 6, col = (i & 63) * 4;
         const uint8_t *p = s_wf + row * kPitch + col;
         const uint32_t mid = *reinterpret_cast<const uint32_t *>(p);
         const uint32_t up = row > 0 ? *reinterpret_cast<const uint32_t *>(p - kPitch) : mid;              // missing neighbour:
         const uint32_t dn = row + 1 < kNumBlocks ? *reinterpret_cast<const uint32_t *>(p + kPitch) : mid;  // p - p = 0
-        const int left = col > 0 ? p[-1] : 0, right = col + 4 < 256 ? p[4] : 0;
+        const int left = col > 0 ? p[-1] : (int)(mid & 0xFF) /* p - p = 0: no lower bin */, right = col + 4 < 256 ? p[4] : 0;
         int c[6];
         c[0] = left;
 #pragma unroll
@@ -121,7 +118,6 @@ void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lis
             const int cc = c[j + 1];
             v[j] = (cc - c[j]) + (cc - c[j + 2]) + (cc - (int)((up >> (8 * j)) & 0xFF)) + (cc - (int)((dn >> (8 * j)) & 0xFF));
         }
-        if (col == 0) v[0] = 0;
         if (col == 252) v[3] = 0;
         uint2 packed;
         packed.x = (uint32_t)(v[0] & 0xFFFF) | ((uint32_t)v[1] << 16);
@@ -151,9 +147,10 @@ void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lis
             const uint8_t *pb = s_wf + t0 * kPitch + fc;
             const int16_t *sb = s_s5 + t0 * kSPitch + fc;
             // Costas pattern {3,1,4,0,6,5,2}
-            int score = sync_symbol<0, 3>(pb, sb, t0) + sync_symbol<1, 1>(pb, sb, t0) + sync_symbol<2, 4>(pb, sb, t0) +
-                        sync_symbol<3, 0>(pb, sb, t0) + sync_symbol<4, 6>(pb, sb, t0) + sync_symbol<5, 5>(pb, sb, t0) +
-                        sync_symbol<6, 2>(pb, sb, t0);
+            const bool f_gt0 = fc > 0;
+            int score = sync_symbol<0, 3>(pb, sb, t0, f_gt0) + sync_symbol<1, 1>(pb, sb, t0, f_gt0) + sync_symbol<2, 4>(pb, sb, t0, f_gt0) +
+                        sync_symbol<3, 0>(pb, sb, t0, f_gt0) + sync_symbol<4, 6>(pb, sb, t0, f_gt0) + sync_symbol<5, 5>(pb, sb, t0, f_gt0) +
+                        sync_symbol<6, 2>(pb, sb, t0, f_gt0);
             {
                 const float fs_ = (float)score;
                 score = (int)(fs_ * rnavg + __builtin_copysignf(0.004f, fs_));
