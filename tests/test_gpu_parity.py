@@ -433,3 +433,42 @@ def test_end_to_end_other_parameters(oracle, gpu_decoder, frames, cap, min_score
             assert n[k] == rn and dec[k].tobytes() == rdec.tobytes(), frames[k][0]
     finally:
         gpu_decoder.set_params(min_score=10, max_candidates=120, ldpc_iters=20)
+
+
+def test_api_edge_cases_and_errors(gpu_decoder):
+    """empty batches, parameter validation and NULL arguments report through the int return code /
+    ft8gpu_last_error (the reference's void ft8_subsystem has no error channel)"""
+    import ctypes as C
+    import rtlsdr_ft8d_amd as ft8
+    lib = ft8.load_library()
+    h = gpu_decoder.h
+    # empty batch: nothing to do, success, outputs untouched
+    dec = np.full((1, 50), 7, np.uint8).view(np.uint8)
+    n = np.array([-5], np.int32)
+    assert lib.ft8gpu_decode_batch(h, 0, 0, 0, 0, ft8.HOST_PTRS) == 0
+    iq = np.zeros((0, 2, 48000), np.float32)
+    d, nn = gpu_decoder.decode_batch(iq)
+    assert d.shape == (0, 50) and nn.shape == (0,)
+    # NULL arrays / negative counts
+    assert lib.ft8gpu_decode_batch(h, 0, 1, 0, 0, ft8.HOST_PTRS) != 0 and b"NULL" in lib.ft8gpu_last_error()
+    assert lib.ft8gpu_decode_batch(h, 0, -1, 0, 0, ft8.HOST_PTRS) != 0
+    assert lib.ft8gpu_waterfall(h, 0, 1, 0, ft8.HOST_PTRS) != 0
+    # parameter validation (rtlsdr_ft8d.h:43-45 made run-time)
+    for bad in [dict(max_candidates=0), dict(max_candidates=ft8.load_library() and 1025), dict(ldpc_iters=0), dict(min_score=40000)]:
+        with pytest.raises(ft8.Ft8GpuError):
+            gpu_decoder.set_params(**bad)
+    assert (gpu_decoder.params.min_score, gpu_decoder.params.max_candidates, gpu_decoder.params.ldpc_iters) == (10, 120, 20)
+    # a context on a GPU that does not exist
+    with pytest.raises(ft8.Ft8GpuError):
+        ft8.Decoder(device=99, max_frames=1)
+    with pytest.raises(ft8.Ft8GpuError):
+        ft8.Decoder(device=0, max_frames=0)
+    # RX front end argument checks
+    assert lib.ft8gpu_rx_decimate(h, 0, 1, 800, 0, 0, ft8.HOST_PTRS) != 0
+    raw = np.zeros(2 * 804, np.uint8)
+    out = np.zeros((1, 2, 48000), np.float32)
+    assert lib.ft8gpu_rx_decimate(h, raw.ctypes.data, 1, 804, out.ctypes.data, 0, ft8.HOST_PTRS) != 0      # 804 % 8 != 0
+    assert b"multiple of 8" in lib.ft8gpu_last_error()
+    # timing is off unless enabled
+    with pytest.raises(ft8.Ft8GpuError):
+        gpu_decoder.timings()
