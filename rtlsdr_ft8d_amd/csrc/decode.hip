@@ -162,14 +162,15 @@ __device__ __forceinline__ void phase_tanh(const float (&x)[10], const int (&slo
     }
 }
 
-// checks -> bits: tov[n][m_idx] = -2 * fast_atanh(product of the other toc of the row)
+// checks -> bits: tov[n][m_idx] = -2 * fast_atanh(product of the other toc of the row).  The state kept
+// in registers is ah = fast_atanh(...) itself, i.e. tov = -2 * ah exactly (see "half domain" below).
 template <bool FAST>
-__device__ __forceinline__ void phase_atanh(const float (&P)[10], float (&tov)[9]) {
+__device__ __forceinline__ void phase_atanh(const float (&P)[10], float (&ah)[9]) {
 #pragma unroll
     for (int p = 0; p < 5; ++p) {
-        const f2 t = -2 * atanh_pair<FAST>(f2{ P[2 * p], P[2 * p + 1] });
-        tov[2 * p] = t.x;
-        if (p < 4) tov[2 * p + 1] = t.y;
+        const f2 t = atanh_pair<FAST>(f2{ P[2 * p], P[2 * p + 1] });
+        ah[2 * p] = t.x;
+        if (p < 4) ah[2 * p + 1] = t.y;
     }
 }
 
@@ -275,19 +276,48 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
     }
 
     // ---- bp_decode ---------------------------------------------------------------------------
-    float tov[9];
+    // Half domain.  The reference adds tov = -2*atanh(.) to the LLR and then forms x = -Tnm/2.  Scaling
+    // by a power of two commutes with every rounding as long as nothing is subnormal, so with
+    // ah = atanh(.) and cwh = -cw/2 the very same bits come out of x = (cwh + ah_a) + ah_b, and the
+    // hard decision (cw + tov0 + tov1 + tov2 > 0) is ((cwh + ah0) + ah1) + ah2 < 0.  fast_ok (all state
+    // values 0 or >= 2^-59, see guard_key) guarantees the "nothing subnormal" premise; when it does
+    // not hold the sums are formed in the reference's own domain from tov = -2*ah (an exact product).
+    float ah[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) tov[i] = 0.0f;
+    for (int i = 0; i < 9; ++i) ah[i] = 0.0f;
+    float cwh[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) cwh[r] = cw[r] * -0.5f;
     int min_errors = kLdpcM;
     uint64_t B0 = 0, B1 = 0, B2 = 0;
     int iter = 0;
-    bool fast_ok = !force_ieee_div;     // every tov is 0 or >= 2^-59 (true for the initial zeros)
+    bool fast_ok = !force_ieee_div;     // every state value is 0 or >= 2^-59 (true for the initial zeros)
     for (; iter < max_iters; ++iter) {
-        // hard decision (tov = 0 in iteration 0)
+        // hard decision (tov = 0 in iteration 0) and Tnm / x for the lane's nine edges
+        // (lanes without a third variable compute on zeros and write to the spare row)
         bool bit[3];
+        float x[10];
+        if (fast_ok) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
-            bit[r] = has[r] && ((((cw[r] + tov[3 * r]) + tov[3 * r + 1]) + tov[3 * r + 2]) > 0.0f);
+            for (int r = 0; r < 3; ++r) {
+                const float u = cwh[r] + ah[3 * r];
+                bit[r] = has[r] && (((u + ah[3 * r + 1]) + ah[3 * r + 2]) < 0.0f);
+                x[3 * r + 0] = (cwh[r] + ah[3 * r + 1]) + ah[3 * r + 2];
+                x[3 * r + 1] = u + ah[3 * r + 2];
+                x[3 * r + 2] = u + ah[3 * r + 1];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float v0 = -2 * ah[3 * r], v1 = -2 * ah[3 * r + 1], v2 = -2 * ah[3 * r + 2];   // tov
+                const float u = cw[r] + v0;
+                bit[r] = has[r] && (((u + v1) + v2) > 0.0f);
+                x[3 * r + 0] = ((cw[r] + v1) + v2) * -0.5f;    // == -Tnm / 2 bit for bit (scaling by a power of two)
+                x[3 * r + 1] = (u + v2) * -0.5f;
+                x[3 * r + 2] = (u + v1) * -0.5f;
+            }
+        }
+        x[9] = 0.0f;
         B0 = __ballot(bit[0]);
         B1 = __ballot(bit[1]);
         B2 = __ballot(bit[2]);
@@ -306,19 +336,6 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
         }
 
         // ---- bits -> checks ------------------------------------------------------------------
-        // (lanes without a third variable compute on zeros and write to the spare row)
-        float x[10];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const float u = cw[r] + tov[3 * r];
-            const float t0 = (cw[r] + tov[3 * r + 1]) + tov[3 * r + 2];
-            const float t1 = u + tov[3 * r + 2];
-            const float t2 = u + tov[3 * r + 1];
-            x[3 * r + 0] = t0 * -0.5f;          // == -t0 / 2 bit for bit (scaling by a power of two)
-            x[3 * r + 1] = t1 * -0.5f;
-            x[3 * r + 2] = t2 * -0.5f;
-        }
-        x[9] = 0.0f;
         if (fast_ok) phase_tanh<true>(x, slot, toc);
         else phase_tanh<false>(x, slot, toc);
         wave_lds_sync();
@@ -354,8 +371,8 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
         }
         P[9] = 0.0f;
         fast_ok = __all(gmin >= kGuardMin) && !force_ieee_div;       // wave-uniform; also governs the next tanh phase
-        if (fast_ok) phase_atanh<true>(P, tov);
-        else phase_atanh<false>(P, tov);
+        if (fast_ok) phase_atanh<true>(P, ah);
+        else phase_atanh<false>(P, ah);
         // (the next iteration's toc stores hit only this lane's own slots; LDS is in order per wave)
     }
 
