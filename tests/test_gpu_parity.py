@@ -472,3 +472,54 @@ def test_api_edge_cases_and_errors(gpu_decoder):
     # timing is off unless enabled
     with pytest.raises(ft8.Ft8GpuError):
         gpu_decoder.timings()
+
+
+def test_decode_randomised_waterfall_sweep(oracle, gpu_decoder):
+    """3 840 candidates over waterfalls built to stress the float paths of the BP kernel: saturated random
+    bytes, two-level maps (huge normalisation factors), nearly constant maps with sparse spikes (many zero
+    LLRs = erasures, exact zeros inside BP), smooth gradients, and real-looking noise with planted tones.
+    Every candidate's ldpc_errors / iterations / packed bits / CRC / text must equal the oracle's."""
+    rng = np.random.default_rng(2024)
+    mags = []
+    for k in range(32):
+        kind = k % 8
+        if kind == 0:
+            m = rng.integers(0, 256, MAG, dtype=np.uint8)
+        elif kind == 1:
+            m = (100 + rng.integers(0, 2, MAG)).astype(np.uint8)                      # two adjacent levels
+        elif kind == 2:
+            m = np.full(MAG, 90, np.uint8)
+            idx = rng.integers(0, MAG, 3000)
+            m[idx] = rng.integers(91, 140, idx.size)                                  # sparse spikes on a flat floor
+        elif kind == 3:
+            m = (np.arange(MAG) % 251).astype(np.uint8)                               # sawtooth
+        elif kind == 4:
+            m = np.clip(rng.normal(120, 6, MAG), 0, 255).astype(np.uint8)             # noise floor
+        elif kind == 5:
+            m = np.clip(rng.normal(120, 6, MAG), 0, 255).astype(np.uint8).reshape(92, 2, 2, 256)
+            for _ in range(30):                                                       # planted tone ladders
+                f, t0 = rng.integers(0, 248), rng.integers(0, 12)
+                for s in range(79):
+                    m[min(t0 + s, 91), :, :, f + rng.integers(0, 8)] += 40
+            m = m.reshape(MAG)
+        elif kind == 6:
+            m = (rng.integers(0, 4, MAG) * 85).astype(np.uint8)                       # four levels, full range
+        else:
+            m = np.clip(rng.normal(20, 30, MAG), 0, 255).astype(np.uint8)             # clipped at zero
+        mags.append(m)
+    mags = np.stack(mags)
+    cd = gpu_decoder.find_sync(mags[:1])[0].dtype
+    cands = np.zeros((32, 120), cd)
+    counts = np.full(32, 120, np.int32)
+    for k in range(32):
+        for c in range(120):
+            cands[k, c] = (rng.integers(10, 60), rng.integers(-12, 24), rng.integers(0, 249), rng.integers(0, 2), rng.integers(0, 2))
+    total = conv = 0
+    for a in range(0, 32, 16):
+        st = gpu_decoder.decode_candidates(mags[a:a + 16], cands[a:a + 16], counts[a:a + 16])
+        for k in range(16):
+            ref = _oracle_status(oracle, mags[a + k], cands[a + k], 20)
+            _compare_status(f"sweep{a + k}", st[k], ref)
+            total += len(ref)
+            conv += sum(r["ldpc_errors"] == 0 for r in ref)
+    assert total == 3840
