@@ -111,10 +111,10 @@ __device__ __forceinline__ f2 atanh_pair(f2 x) {
 // ONE guard per iteration, on the nine row products P of the lane, with T = 2^-59, covers both
 // division sites of the following work:
 //   * fast_atanh(P): numerator P*(945 - 735P^2 + 64P^4) with |P| <= 1.0072^6, so |numerator| >= 200|P|;
-//   * tov = -2*fast_atanh(P) then satisfies tov == 0 or |tov| >= 2^-59 (|atanh_r(P)| >= |P|), and the
-//     LLRs are 0 or >= 0.019 (an integer times sqrt(24/variance), variance <= 255^2).  Any sum of two
-//     or three floats that are each 0 or >= 2^-59 is 0 or >= 2^-59 * 2^-23, hence the next
-//     iteration's x = -Tnm/2 is 0 or >= 2^-83, and fast_tanh's numerator x*(945 + ...) >= 945|x|.
+//   * the state ah = fast_atanh(P) (tov = -2*ah) then satisfies ah == 0 or |ah| >= 2^-59 (|atanh_r(P)| >= |P|),
+//     and the halved LLRs cwh are 0 or >= 0.0095 (an integer times sqrt(24/variance)/2, variance <= 255^2).
+//     Any sum of two or three floats that are each 0 or >= 2^-59 is 0 or >= 2^-82 (all are multiples of
+//     2^-82), hence the next iteration's x is 0 or >= 2^-82, and fast_tanh's numerator x*(945 + ...) >= 945|x|.
 // Both are far above v_div_scale's 2^-103 rescaling threshold.  Large, infinite and NaN values need
 // no guard: |x| > 4.97 is overridden by fast_tanh's clamp in either division form, the products are
 // bounded, and NaN stays NaN through both forms.  Iteration 0 starts from tov = 0.
