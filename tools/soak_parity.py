@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Mass parity run: many batches of on-device synthetic frames with varying density and SNR; every frame's spot
+records from the GPU are compared byte for byte with the CPU oracle (all host cores).
+usage: tools/soak_parity.py [--batches 40] [--frames 4096]"""
+import argparse, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batches", type=int, default=40)
+    ap.add_argument("--frames", type=int, default=4096)
+    args = ap.parse_args()
+    import torch
+    import oracle_lib as O
+    import rtlsdr_ft8d_amd as ft8
+    from rtlsdr_ft8d_amd import workload
+    sys.path.insert(0, ROOT)
+    from bench import usable_cores
+    cores = usable_cores()
+    B = args.frames
+    _, tones = workload.message_pool()
+    rng = np.random.default_rng(123)
+    dec = ft8.Decoder(device=0, max_frames=B)
+    iq = torch.empty((B, 2, ft8.NSAMPLES), dtype=torch.float32, device="cuda")
+    spots = torch.zeros((B, 1400), dtype=torch.uint8, device="cuda")
+    nres = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    bad = total = msgs = 0
+    t0 = time.time()
+    for b in range(args.batches):
+        nsig = int(rng.integers(0, 61))
+        lo_snr = float(rng.uniform(-26, -10)); hi_snr = lo_snr + float(rng.uniform(2, 20))
+        cap = int(rng.choice([120, 120, 120, 60, 240, 480]))
+        dec.set_params(max_candidates=cap)
+        sig, _ = workload.frame_signals(1_000_000 + b * B, B, nsig, tones, snr_range=(lo_snr, hi_snr))
+        dec.synth_frames(sig, B, nsig, 1.0, 777 + b, iq)
+        spots.zero_()
+        dec.decode_batch_dev(iq, B, spots, nres)
+        dec.synchronize()
+        g = spots.cpu().numpy().view(ft8.RESULT_DTYPE).reshape(B, 50)
+        gn = nres.cpu().numpy()
+        rdec, rn = O.subsystem_batch(iq.cpu().numpy(), O.default_params(10, cap, 20), cores)
+        mism = [k for k in range(B) if gn[k] != rn[k] or g[k].tobytes() != rdec[k].tobytes()]
+        bad += len(mism); total += B; msgs += int(gn.sum())
+        print(f"batch {b}: nsig {nsig} snr [{lo_snr:.0f},{hi_snr:.0f}] cap {cap}: {int(gn.sum())} messages, mismatching frames {len(mism)}", flush=True)
+    print(json.dumps({"frames": total, "messages": msgs, "mismatching_frames": bad, "seconds": round(time.time() - t0, 1)}))
+
+
+if __name__ == "__main__":
+    main()
