@@ -8,7 +8,7 @@
  *                            noise from unseeded rand()), decode, check call/locator
  *   ft8_replay file.iq|.c2   file replay as decodeRecordedFile() (rtlsdr_ft8d.c:859-887)
  *
- * Spots are printed in the layout of printSpots() (rtlsdr_ft8d.c:643-663), without the timestamp.
+ * Spots are printed in the layout of printSpots() (rtlsdr_ft8d.c:643-663).
  * Build:  gcc -O2 -std=gnu17 -Iinclude examples/ft8_replay.c -Lrtlsdr_ft8d_amd -lft8gpu \
  *             -Wl,-rpath,$PWD/rtlsdr_ft8d_amd -lm -o examples/ft8_replay
  */
@@ -22,14 +22,14 @@
 
 static struct decoder_results dec_results[50];       /* rtlsdr_ft8d.c:67 */
 
+/* the layout of printSpots(), rtlsdr_ft8d.c:643-663 (every counted slot is printed, as upstream does,
+ * including slots of non-CQ messages that ft8_subsystem leaves untouched; the no-spot line carries no date here) */
 static void print_spots(int32_t n_results, uint32_t dialfreq) {
     if (n_results == 0) { printf("No spot\n"); return; }
     printf("  Score     Freq       Call    Loc\n");
-    for (int32_t i = 0; i < n_results; i++) {
-        if (dec_results[i].call[0] == 0) continue;   /* slot of a non-CQ message (never written) */
-        printf("  %5d %10u %10s %6s\n", dec_results[i].snr, dec_results[i].freq + dialfreq,
+    for (int32_t i = 0; i < n_results; i++)
+        printf("     %2d %8d %10s %6s\n", dec_results[i].snr, (int)(dec_results[i].freq + dialfreq),
                dec_results[i].call, dec_results[i].loc);
-    }
 }
 
 static float white_gaussian_noise(float factor) {    /* rtlsdr_ft8d.c:890-910 */

@@ -416,7 +416,7 @@ def test_c_caller_self_test_and_file_replay(oracle, tmp_path):
     fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
     assert oracle.lib().ft8o_read_raw_iq(fp(i2), fp(q2), str(tmp_path / "selftest.iq").encode()) == 48000
     dec, n = oracle.subsystem(i2, q2)
-    assert n == 1 and f"{int(dec[0]['snr']):5d}" in out.stdout
+    assert n == 1 and f"     {int(dec[0]['snr']):2d} {int(dec[0]['freq']):8d} {dec[0]['call'].decode():>10s} {dec[0]['loc'].decode():>6s}" in out.stdout
 
 
 @pytest.mark.parametrize("cap,min_score,iters", [(33, 10, 20), (7, 12, 5), (250, 8, 20)])
