@@ -9,6 +9,10 @@
  *   one frame = 15 s at 3200 sps = 48000 complex samples, planar float32: I[48000] then Q[48000].
  *   A batch is `nframes` such frames back to back: iq[nframes][2][48000].
  *   waterfall = uint8 mag[92][2][2][256] (block, time_sub, freq_sub, bin) = 94208 bytes per frame.
+ *
+ * Environment switches (read once): FT8GPU_DEVICE=<n> GPU used by the drop-in ft8_subsystem (default 0);
+ * FT8GPU_OVERLAP=0 disables the two-half overlapped pipeline for batches >= 512 frames;
+ * FT8GPU_FORCE_IEEE_DIV=1 makes the LDPC kernel use the compiler's IEEE division everywhere (test hook).
  */
 #ifndef FT8GPU_H
 #define FT8GPU_H
