@@ -101,6 +101,9 @@ struct ft8gpu_ctx {
                                            // while the main stream works on the other half
     hipEvent_t dep[6]{};                   // cross-stream dependencies (no timing)
     bool overlap = true;
+    hipStream_t copy = nullptr;            // host-buffer calls: uploads chunk k+1 while chunk k is decoded
+    static constexpr int kCopyEvents = 4;
+    hipEvent_t copied[kCopyEvents]{};
 
     Ft8Tables *d_tab = nullptr;
     float *d_iq = nullptr;                 // staging for host-pointer calls
@@ -261,6 +264,8 @@ static int create_body(ft8gpu_ctx *c) {
     for (auto &slot : c->ev) for (auto &e : slot) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     for (auto &e : c->dep) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+    for (auto &e : c->copied) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     { const char *e = getenv("FT8GPU_OVERLAP"); c->overlap = !(e && e[0] == '0'); }
 
     Ft8Tables *h = (Ft8Tables *)malloc(sizeof(Ft8Tables));
@@ -320,6 +325,9 @@ void ft8gpu_destroy(ft8gpu_ctx *c) {
     for (auto &slot : c->ev) for (auto &e : slot) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->dep) if (e) (void)hipEventDestroy(e);
     if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->copy) (void)hipStreamSynchronize(c->copy);
+    for (auto &e : c->copied) if (e) (void)hipEventDestroy(e);
+    if (c->copy) (void)hipStreamDestroy(c->copy);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -403,6 +411,8 @@ void ft8gpu_dev_free(void *p) { if (p) (void)hipFree(p); }
 int ft8gpu_memcpy_h2d(void *d, const void *s, size_t n) { HIP_TRY(hipMemcpy(d, s, n, hipMemcpyHostToDevice)); return 0; }
 int ft8gpu_memcpy_d2h(void *d, const void *s, size_t n) { HIP_TRY(hipMemcpy(d, s, n, hipMemcpyDeviceToHost)); return 0; }
 
+static constexpr int kHostChunk = 512;      // frames per upload chunk of a host-buffer batch
+
 #define CHECK_COMMON(c, n)                                                              \
     if (!(c)) return fail("ctx is NULL");                                               \
     if ((n) < 0) return fail("nframes < 0");                                            \
@@ -420,11 +430,25 @@ int ft8gpu_decode_batch(ft8gpu_ctx *c, const float *iq, int nframes, struct deco
             if (run_pipeline(c, iq + f0 * frame_floats, n, decodes + (size_t)f0 * kMaxMessages, n_results + f0)) return -1;
         } else {
             if (!c->d_iq) HIP_TRY(hipMalloc(&c->d_iq, (size_t)c->max_frames * frame_floats * sizeof(float)));
-            HIP_TRY(hipMemcpyAsync(c->d_iq, iq + f0 * frame_floats, n * frame_floats * sizeof(float), hipMemcpyHostToDevice, c->stream));
             // slots of non-CQ messages must keep the caller's bytes (rtlsdr_ft8d.c:1509-1520)
             HIP_TRY(hipMemcpyAsync(c->d_decodes, decodes + (size_t)f0 * kMaxMessages,
                                    (size_t)n * kMaxMessages * sizeof(struct decoder_results), hipMemcpyHostToDevice, c->stream));
-            if (run_pipeline(c, c->d_iq, n, c->d_decodes, c->d_nres)) return -1;
+            // the upload is 384 KB per frame and takes longer than the decode: pipeline it in chunks on a
+            // copy stream so that the kernels of chunk k run under the upload of chunk k+1
+            const int chunk = (n > kHostChunk && c->overlap) ? kHostChunk : n;
+            int k = 0;
+            for (int g0 = 0; g0 < n; g0 += chunk, k++) {
+                const int m = (n - g0 < chunk) ? n - g0 : chunk;
+                hipStream_t up = (chunk < n) ? c->copy : c->stream;
+                HIP_TRY(hipMemcpyAsync(c->d_iq + g0 * frame_floats, iq + (f0 + g0) * frame_floats, m * frame_floats * sizeof(float),
+                                       hipMemcpyHostToDevice, up));
+                if (up != c->stream) {
+                    hipEvent_t e = c->copied[k % ft8gpu_ctx::kCopyEvents];
+                    HIP_TRY(hipEventRecord(e, up));
+                    HIP_TRY(hipStreamWaitEvent(c->stream, e, 0));
+                }
+                if (run_pipeline(c, c->d_iq + g0 * frame_floats, m, c->d_decodes + (size_t)g0 * kMaxMessages, c->d_nres + g0)) return -1;
+            }
             HIP_TRY(hipMemcpyAsync(decodes + (size_t)f0 * kMaxMessages, c->d_decodes,
                                    (size_t)n * kMaxMessages * sizeof(struct decoder_results), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipMemcpyAsync(n_results + f0, c->d_nres, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));

@@ -52,7 +52,12 @@ def test_config3_full_batch_properties(oracle):
         with ft8.Decoder(device=0, max_frames=1000) as dec_small:
             dc, nc = _decode_dev(ft8, dec_small, iq, B)
         assert np.array_equal(nc, n1) and dc.tobytes() == d1.tobytes()
-        host_iq = iq[:24].cpu().numpy()
+        # host-buffer entry: uploads are pipelined in 512-frame chunks (ragged last chunk) under the kernels
+        hn = 512 * 2 + 77
+        host_all = iq[:hn].cpu().numpy()
+        dh, nh = dec.decode_batch(host_all)
+        assert np.array_equal(nh, n1[:hn]) and dh.tobytes() == d1[:hn].tobytes()
+        host_iq = host_all[:24]
     # recall / false decodes against what was planted
     found = planted = false_calls = total_calls = 0
     for f in range(B):
