@@ -1,7 +1,7 @@
 /*
  * ft8_replay.c -- a C caller of libft8gpu.so that uses ONLY the three symbols the reference daemon
  * itself uses (initFFTW / ft8_subsystem / freeFFTW, rtlsdr_ft8d.h:155-156,164) plus the library's
- * .iq/.c2 readers.  It walks the same steps as the reference's own callers:
+ * .iq/.c2 readers and spot-table formatter.  It walks the same steps as the reference's own callers:
  *
  *   ft8_replay -t            self-test: synthesise "CQ K1JT FN20QI" exactly as decoderSelfTest()
  *                            (rtlsdr_ft8d.c:913-972: plain FSK at 50 Hz, amplitude 0.5, Box-Muller
@@ -17,19 +17,21 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "ft8gpu.h"
 
 static struct decoder_results dec_results[50];       /* rtlsdr_ft8d.c:67 */
 
-/* the layout of printSpots(), rtlsdr_ft8d.c:643-663 (every counted slot is printed, as upstream does,
- * including slots of non-CQ messages that ft8_subsystem leaves untouched; the no-spot line carries no date here) */
+/* printSpots(), rtlsdr_ft8d.c:643-663, through the library's formatter (every counted slot is printed, as
+ * upstream does, including slots of non-CQ messages that ft8_subsystem leaves untouched) */
 static void print_spots(int32_t n_results, uint32_t dialfreq) {
-    if (n_results == 0) { printf("No spot\n"); return; }
-    printf("  Score     Freq       Call    Loc\n");
-    for (int32_t i = 0; i < n_results; i++)
-        printf("     %2d %8d %10s %6s\n", dec_results[i].snr, (int)(dec_results[i].freq + dialfreq),
-               dec_results[i].call, dec_results[i].loc);
+    char text[64 + 48 * 50];
+    time_t now = time(NULL);
+    struct tm *gtm = gmtime(&now);
+    ft8gpu_format_spots(dec_results, n_results, dialfreq, gtm->tm_year + 1900, gtm->tm_mon + 1, gtm->tm_mday,
+                        gtm->tm_hour, gtm->tm_min, text, sizeof text);
+    fputs(text, stdout);
 }
 
 static float white_gaussian_noise(float factor) {    /* rtlsdr_ft8d.c:890-910 */

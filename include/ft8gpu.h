@@ -183,6 +183,34 @@ int ft8gpu_synth_frames(ft8gpu_ctx *ctx, const ft8gpu_synth_signal *signals, int
 int ft8gpu_rx_decimate(ft8gpu_ctx *ctx, const uint8_t *raw, int ncaptures, size_t npairs,
                        float *iq, int normalise, int flags);
 
+/* ---- spot reporting wire formats ------------------------------------
+ * The bytes postSpots() (rtlsdr_ft8d.c:365-590) assembles for report.pskreporter.info:4739 (IPFIX:
+ * 16-byte header, receiver and sender template sets, receiver record, one sender record per slot
+ * of decodes[0..n_results)), built for a whole batch of spot lists at once; nothing is sent.
+ * Reference behaviour kept: every slot below n_results is emitted, also the untouched slots of
+ * non-CQ messages (:494-533); a record is started only while the sender block is <= 1200 bytes
+ * (:497); SNR byte = (int8)snr - 20 (:511); both data blocks are zero-padded to 4 bytes.
+ * Fenced: call / loc are read up to 12 / 6 characters (the reference's strlen has no bound). */
+#define FT8GPU_DATAGRAM_STRIDE 1408        /* >= the largest datagram (168 + 1236 bytes) */
+typedef struct {
+    char     rcall[13];        /* dec_options.rcall, rtlsdr_ft8d.h:132 */
+    char     rloc[7];          /* dec_options.rloc,  rtlsdr_ft8d.h:133 */
+    char     app_version[32];  /* pskreporter_app_version, rtlsdr_ft8d.c:72 */
+    uint32_t dial_freq;        /* dec_options.freq, added to every spot's audio offset (:507) */
+    uint32_t unixtime;         /* header export time and spot time (:445, :531) unless unixtimes != NULL */
+    uint32_t sequence;         /* 1 in the reference (:425) */
+    uint32_t random_id;        /* :430-435 */
+} ft8gpu_report_info;
+/* decodes: [nframes][50], n_results: [nframes], unixtimes: [nframes] or NULL,
+ * datagrams: [nframes][FT8GPU_DATAGRAM_STRIDE] (bytes past the length are zero), lengths: [nframes] */
+int ft8gpu_pskreporter_datagrams(ft8gpu_ctx *ctx, const struct decoder_results *decodes,
+                                 const int32_t *n_results, int nframes, const ft8gpu_report_info *info,
+                                 const uint32_t *unixtimes, uint8_t *datagrams, int32_t *lengths, int flags);
+/* the stdout table of printSpots() (:643-663) for one frame's spot list, into `out` (NUL-terminated,
+ * truncated to cap); returns the untruncated length.  Host-side text formatting, no GPU involved. */
+int ft8gpu_format_spots(const struct decoder_results *decodes, int32_t n_results, uint32_t dial_freq,
+                        int year, int month, int mday, int hour, int minute, char *out, size_t cap);
+
 /* device memory helpers so that a plain C caller needs no HIP headers */
 void *ft8gpu_dev_alloc(size_t bytes);
 void  ft8gpu_dev_free(void *p);

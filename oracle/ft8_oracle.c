@@ -1292,3 +1292,102 @@ void ft8o_rx_capture(const unsigned char *raw, size_t nbytes, float *iSamples, f
     if (normalise) ft8o_normalise(iSamples, qSamples, FT8O_NSAMPLES);                                     /* :248-263 */
     if (n_out) *n_out = idx;
 }
+
+/* ================= spot reporting wire formats ================================= */
+
+/* the two IPFIX template sets of rtlsdr_ft8d.c:386-423 as big-endian 16-bit words
+ * (set id, set length, link id, field count, [scope count]; then id, length, enterprise hi, lo per field) */
+static const uint16_t rep_rx_template[18] = {
+    0x0003, 36, 0x9992, 3, 0,
+    0x8002, 0xFFFF, 0x0000, 0x768F,       /* receiver callsign, variable */
+    0x8004, 0xFFFF, 0x0000, 0x768F,       /* receiver locator, variable */
+    0x8008, 0xFFFF, 0x0000, 0x768F,       /* decoder software, variable */
+    0x0000 };                             /* padding */
+static const uint16_t rep_tx_template[30] = {
+    0x0002, 60, 0x9993, 7,
+    0x8001, 0xFFFF, 0x0000, 0x768F,       /* sender callsign, variable */
+    0x8005, 4,      0x0000, 0x768F,       /* frequency */
+    0x8006, 1,      0x0000, 0x768F,       /* SNR */
+    0x800A, 0xFFFF, 0x0000, 0x768F,       /* mode, variable */
+    0x8003, 0xFFFF, 0x0000, 0x768F,       /* sender locator, variable */
+    0x800B, 1,      0x0000, 0x768F,       /* information source */
+    0x0096, 4 };                          /* flowStartSeconds */
+
+static uint32_t rep_w16(unsigned char *p, uint32_t at, uint16_t v) { p[at] = (unsigned char)(v >> 8); p[at + 1] = (unsigned char)v; return at + 2; }
+static uint32_t rep_w32(unsigned char *p, uint32_t at, uint32_t v) { at = rep_w16(p, at, (uint16_t)(v >> 16)); return rep_w16(p, at, (uint16_t)v); }
+static uint32_t rep_str(unsigned char *p, uint32_t at, const char *s, size_t cap) {
+    size_t len = 0;
+    while (len < cap && s[len]) len++;
+    p[at++] = (unsigned char)len;
+    memcpy(p + at, s, len);
+    return at + (uint32_t)len;
+}
+
+int ft8o_pskreporter_datagram(const struct ft8o_decoder_results *dec_results, int32_t n_results,
+                              const ft8o_report_info *info, unsigned char *out) {
+    unsigned char header[16], rx[256], tx[1500];
+    memset(rx, 0, sizeof rx);                                         /* :454 */
+    memset(tx, 0, sizeof tx);                                         /* :486 */
+
+    uint32_t h = 0;                                                   /* :439-450 */
+    h = rep_w16(header, h, 0x000A);
+    h = rep_w16(header, h, 0);
+    h = rep_w32(header, h, info->unixtime);
+    h = rep_w32(header, h, info->sequence);
+    h = rep_w32(header, h, info->random_id);
+
+    uint32_t rxPtr = rep_w16(rx, 0, 0x9992) + 2;                      /* :458-460 */
+    rxPtr = rep_str(rx, rxPtr, info->rcall, 12);                      /* :463-466 */
+    rxPtr = rep_str(rx, rxPtr, info->rloc, 6);                        /* :469-472 */
+    rxPtr = rep_str(rx, rxPtr, info->app_version, 31);                /* :475-478 */
+    if (rxPtr % 4) rxPtr += 4 - rxPtr % 4;                            /* :481-482 */
+
+    uint32_t txPtr = rep_w16(tx, 0, 0x9993) + 2;                      /* :490-492 */
+    if (n_results > FT8O_K_MAX_MESSAGES) n_results = FT8O_K_MAX_MESSAGES;
+    for (int32_t i = 0; i < n_results; i++) {                         /* :494 */
+        if (txPtr > 1200) break;                                      /* :497 */
+        txPtr = rep_str(tx, txPtr, dec_results[i].call, 12);          /* :501-504 */
+        txPtr = rep_w32(tx, txPtr, (uint32_t)dec_results[i].freq + info->dial_freq);   /* :507 */
+        { int8_t v = (int8_t)((int8_t)dec_results[i].snr - 20); tx[txPtr++] = (unsigned char)v; }   /* :511 */
+        txPtr = rep_str(tx, txPtr, "FT8", 3);                         /* :515-518 */
+        txPtr = rep_str(tx, txPtr, dec_results[i].loc, 6);            /* :521-524 */
+        tx[txPtr++] = 1;                                              /* :527 */
+        txPtr = rep_w32(tx, txPtr, info->unixtime);                   /* :531 */
+    }
+    if (txPtr % 4) txPtr += 4 - txPtr % 4;                            /* :536-537 */
+
+    const uint32_t full = 16 + 36 + 60 + rxPtr + txPtr;               /* :541 */
+    rep_w16(rx, 2, (uint16_t)rxPtr);                                  /* :542 */
+    rep_w16(tx, 2, (uint16_t)txPtr);                                  /* :543 */
+    rep_w16(header, 2, (uint16_t)full);                               /* :544 */
+
+    uint32_t at = 0;                                                  /* :547-553 */
+    memcpy(out + at, header, 16); at += 16;
+    for (int i = 0; i < 18; i++) at = rep_w16(out, at, rep_rx_template[i]);
+    for (int i = 0; i < 30; i++) at = rep_w16(out, at, rep_tx_template[i]);
+    memcpy(out + at, rx, rxPtr); at += rxPtr;
+    memcpy(out + at, tx, txPtr); at += txPtr;
+    return (int)at;
+}
+
+int ft8o_format_spots(const struct ft8o_decoder_results *dec_results, int32_t n_results, uint32_t dial_freq,
+                      int year, int month, int mday, int hour, int minute, char *out, size_t cap) {
+    size_t at = 0;
+    int k;
+    if (cap) out[0] = 0;
+    if (n_results <= 0) {                                             /* :644-653 */
+        k = snprintf(out, cap, "No spot %04d-%02d-%02d %02d:%02dz\n", year, month, mday, hour, minute);
+        return k;
+    }
+    k = snprintf(out, cap, "  Score     Freq       Call    Loc\n");   /* :655 */
+    at += (size_t)k;
+    for (int32_t i = 0; i < n_results && i < FT8O_K_MAX_MESSAGES; i++) {   /* :656-662 */
+        char call[13], loc[7];
+        memcpy(call, dec_results[i].call, 12); call[12] = 0;
+        memcpy(loc, dec_results[i].loc, 6); loc[6] = 0;
+        k = snprintf(at < cap ? out + at : NULL, at < cap ? cap - at : 0, "     %2d %8d %10s %6s\n",
+                     dec_results[i].snr, (int)((uint32_t)dec_results[i].freq + dial_freq), call, loc);
+        at += (size_t)k;
+    }
+    return (int)at;
+}

@@ -183,6 +183,25 @@ void ft8o_rx_callback(ft8o_rx_state_t *st, unsigned char *samples, uint32_t samp
 void ft8o_rx_capture(const unsigned char *raw, size_t nbytes, float *iSamples, float *qSamples,
                      uint32_t *n_out, int normalise);
 
+/* postSpots(), rtlsdr_ft8d.c:365-590: the PSKreporter UDP datagram for one frame's spot list (the
+ * reference function returns at its first line, :380, so upstream never sends it; this restates the
+ * bytes it would assemble at :386-561).  Returns the datagram length (fullBlockSize, :541); out must
+ * hold 1536 bytes.  strlen() of call / loc is bounded by the field sizes. */
+typedef struct {
+    char     rcall[13];
+    char     rloc[7];
+    char     app_version[32];
+    uint32_t dial_freq;
+    uint32_t unixtime;
+    uint32_t sequence;
+    uint32_t random_id;
+} ft8o_report_info;
+int ft8o_pskreporter_datagram(const struct ft8o_decoder_results *dec_results, int32_t n_results,
+                              const ft8o_report_info *info, unsigned char *out);
+/* printSpots(), rtlsdr_ft8d.c:643-663, into a string; returns its length (year/month as printed) */
+int ft8o_format_spots(const struct ft8o_decoder_results *dec_results, int32_t n_results, uint32_t dial_freq,
+                      int year, int month, int mday, int hour, int minute, char *out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

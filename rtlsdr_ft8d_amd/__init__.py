@@ -40,6 +40,16 @@ class Timings(C.Structure):
                 ("launches_per_stage", C.c_int32)]
 
 
+class ReportInfo(C.Structure):
+    """ft8gpu_report_info: receiver identity and the per-datagram constants of postSpots() (rtlsdr_ft8d.c:365-590)"""
+    _fields_ = [("rcall", C.c_char * 13), ("rloc", C.c_char * 7), ("app_version", C.c_char * 32),
+                ("dial_freq", C.c_uint32), ("unixtime", C.c_uint32), ("sequence", C.c_uint32),
+                ("random_id", C.c_uint32)]
+
+
+DATAGRAM_STRIDE = 1408
+
+
 class Ft8GpuError(RuntimeError):
     pass
 
@@ -49,7 +59,7 @@ ABI_SYMBOLS = [
     "ft8gpu_get_timings", "ft8gpu_synchronize", "ft8gpu_last_error", "ft8gpu_device_count",
     "ft8gpu_decode_batch", "ft8gpu_waterfall", "ft8gpu_find_sync", "ft8gpu_score_map",
     "ft8gpu_decode_candidates", "ft8gpu_collect_spots", "ft8gpu_pack77_std", "ft8gpu_encode",
-    "ft8gpu_synth_frames", "ft8gpu_rx_decimate", "ft8gpu_dev_alloc", "ft8gpu_dev_free", "ft8gpu_memcpy_h2d", "ft8gpu_memcpy_d2h",
+    "ft8gpu_synth_frames", "ft8gpu_rx_decimate", "ft8gpu_pskreporter_datagrams", "ft8gpu_format_spots", "ft8gpu_dev_alloc", "ft8gpu_dev_free", "ft8gpu_memcpy_h2d", "ft8gpu_memcpy_d2h",
     "initFFTW", "freeFFTW", "ft8_subsystem", "ft8gpu_read_raw_iq", "ft8gpu_read_c2", "ft8gpu_write_raw_iq",
 ]
 
@@ -96,6 +106,8 @@ def load_library():
     L.ft8gpu_encode.restype = None
     L.ft8gpu_synth_frames.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, C.c_uint64, vp]
     L.ft8gpu_rx_decimate.argtypes = [vp, vp, C.c_int, C.c_size_t, vp, C.c_int, C.c_int]
+    L.ft8gpu_pskreporter_datagrams.argtypes = [vp, vp, vp, C.c_int, C.POINTER(ReportInfo), vp, vp, vp, C.c_int]
+    L.ft8gpu_format_spots.argtypes = [vp, C.c_int32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t]
     L.ft8gpu_dev_alloc.argtypes = [C.c_size_t]
     L.ft8gpu_dev_alloc.restype = vp
     L.ft8gpu_dev_free.argtypes = [vp]
@@ -274,11 +286,42 @@ class Decoder:
     def rx_decimate_dev(self, raw_dev, ncaptures, npairs, iq_dev, normalise=True):
         _check(self.lib.ft8gpu_rx_decimate(self.h, _ptr(raw_dev), ncaptures, npairs, _ptr(iq_dev), int(normalise), DEVICE_PTRS))
 
+    def pskreporter_datagrams(self, decodes, n_results, info, unixtimes=None):
+        """decodes: [n][50] RESULT_DTYPE, n_results: [n] -> (uint8 [n][DATAGRAM_STRIDE], int32 [n] lengths)"""
+        decodes = np.ascontiguousarray(decodes)
+        n_results = np.ascontiguousarray(n_results, np.int32)
+        n = n_results.shape[0]
+        assert decodes.dtype == RESULT_DTYPE and decodes.size == n * MAX_MESSAGES
+        out = np.zeros((n, DATAGRAM_STRIDE), np.uint8)
+        lengths = np.zeros(n, np.int32)
+        t = None if unixtimes is None else np.ascontiguousarray(unixtimes, np.uint32)
+        _check(self.lib.ft8gpu_pskreporter_datagrams(self.h, decodes.ctypes.data, n_results.ctypes.data, n, C.byref(info),
+                                                     None if t is None else t.ctypes.data, out.ctypes.data,
+                                                     lengths.ctypes.data, HOST_PTRS))
+        return out, lengths
+
+    def pskreporter_datagrams_dev(self, decodes_dev, n_results_dev, nframes, info, unixtimes_dev, datagrams_dev, lengths_dev):
+        _check(self.lib.ft8gpu_pskreporter_datagrams(self.h, _ptr(decodes_dev), _ptr(n_results_dev), nframes, C.byref(info),
+                                                     None if unixtimes_dev is None else _ptr(unixtimes_dev),
+                                                     _ptr(datagrams_dev), _ptr(lengths_dev), DEVICE_PTRS))
+
     def synth_frames(self, signals, nframes, nsig, noise_sigma, seed, iq_dev):
         signals = np.ascontiguousarray(signals)
         assert signals.dtype == SIGNAL_DTYPE and signals.size == nframes * nsig
         _check(self.lib.ft8gpu_synth_frames(self.h, signals.ctypes.data, nframes, nsig, float(noise_sigma),
                                             int(seed), _ptr(iq_dev)))
+
+
+def format_spots(decodes, n_results, dial_freq, year, month, mday, hour, minute):
+    """printSpots() (rtlsdr_ft8d.c:643-663) as a string"""
+    L = load_library()
+    decodes = np.ascontiguousarray(decodes)
+    assert decodes.dtype == RESULT_DTYPE
+    buf = C.create_string_buffer(64 + 48 * MAX_MESSAGES)
+    n = L.ft8gpu_format_spots(decodes.ctypes.data, int(n_results), int(dial_freq), year, month, mday, hour, minute, buf, len(buf))
+    if n < 0:
+        raise Ft8GpuError("ft8gpu_format_spots failed")
+    return buf.value.decode()
 
 
 def ft8_subsystem(i_samples, q_samples, decodes=None):

@@ -240,3 +240,31 @@ int32_t ft8gpu_write_raw_iq(const float *iSamples, const float *qSamples, const 
     if (nwrite != 2 * FT8GPU_NSAMPLES) { fprintf(stderr, "Cannot write all the data!\n"); return 0; }
     return FT8GPU_NSAMPLES;
 }
+
+/* ---- the stdout table of printSpots(), rtlsdr_ft8d.c:643-663 --------------------------------- */
+static void emit(char *out, size_t cap, size_t *at, const char *line, int len) {
+    if (len < 0) return;
+    if (out && *at < cap) {
+        size_t room = cap - *at - 1, n = (size_t)len < room ? (size_t)len : room;
+        memcpy(out + *at, line, n);
+        out[*at + n] = 0;
+    }
+    *at += (size_t)len;
+}
+
+int ft8gpu_format_spots(const struct decoder_results *decodes, int32_t n_results, uint32_t dial_freq,
+                        int year, int month, int mday, int hour, int minute, char *out, size_t cap) {
+    char line[96];
+    size_t at = 0;
+    if (out && cap) out[0] = 0;
+    if (n_results <= 0) {                                                    /* :644-653 */
+        emit(out, cap, &at, line, snprintf(line, sizeof line, "No spot %04d-%02d-%02d %02d:%02dz\n", year, month, mday, hour, minute));
+        return (int)at;
+    }
+    if (!decodes) return -1;
+    emit(out, cap, &at, line, snprintf(line, sizeof line, "  Score     Freq       Call    Loc\n"));   /* :655 */
+    for (int32_t i = 0; i < n_results && i < FT8GPU_K_MAX_MESSAGES; i++)     /* :656-662 */
+        emit(out, cap, &at, line, snprintf(line, sizeof line, "     %2d %8d %10.12s %6.6s\n", decodes[i].snr,
+                                          (int)((uint32_t)decodes[i].freq + dial_freq), decodes[i].call, decodes[i].loc));
+    return (int)at;
+}

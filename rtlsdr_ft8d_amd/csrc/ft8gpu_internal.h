@@ -54,3 +54,15 @@ hipError_t launch_synth(const ft8gpu_synth_signal *sig_dev, int nframes, int nsi
 hipError_t decode_tables_init(hipStream_t s);   // uploads the LDPC edge tables used by the BP kernel
 hipError_t launch_rx(const uint8_t *raw, int ncaptures, size_t npairs, void *scratch_sums, void *scratch_base,
                      float *iq, int normalise, hipStream_t s);
+
+// f-4: everything of a PSKreporter datagram that does not depend on the frame (header, receiver and
+// sender templates, receiver record), assembled on the host once per call and passed by value
+struct ReportPrefix {
+    unsigned char bytes[192];
+    int32_t  len;
+    uint32_t dial_freq;
+    uint32_t unixtime;
+};
+hipError_t launch_report(const struct decoder_results *decodes, const int32_t *n_results, int nframes,
+                         const ReportPrefix &pre, const uint32_t *unixtimes, uint8_t *datagrams,
+                         int32_t *lengths, hipStream_t s);

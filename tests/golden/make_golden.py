@@ -91,7 +91,41 @@ def main():
     json.dump({"generator": "tests/synth_util.make_frame", "frames": frames},
               open(os.path.join(HERE, "frames.json"), "w"), indent=1)
     print("golden written:", [f["n_results"] for f in frames])
+    report_golden()
+
+
+def report_golden():
+    """report.json: PSKreporter datagrams / stdout tables of the oracle for a few spot lists (f-4).
+    The reference holds no vector for these; the first case is the self-test spot (rtlsdr_ft8d.c:966-971)."""
+    O.build()
+    cases = [
+        ([("K1JT", "FN20", 28, 34)], 1, dict(rcall="N0CALL", rloc="FN20", app_version="rtlsdr-ft8d_v0.3.6",
+                                            dial_freq=14074000, unixtime=1700000000, sequence=1, random_id=0x12345678)),
+        ([("VE2ABC/P", "FN35", 1503, 12), ("", "", 0, 0), ("PA0XYZ", "JO22", 2999, 150)], 3,
+         dict(rcall="VE2XYZ/QRP12", rloc="FN35ab", app_version="x", dial_freq=7074000, unixtime=1739343900, sequence=1, random_id=1)),
+        ([], 0, dict(rcall="A", rloc="B", app_version="", dial_freq=0, unixtime=0, sequence=1, random_id=0)),
+        ([("Q%011d" % k, "AA00aa", k, k) for k in range(50)], 50,
+         dict(rcall="N0CALL", rloc="FN20", app_version="rtlsdr-ft8d_v0.3.6", dial_freq=50313000, unixtime=1700000015, sequence=1, random_id=0xFFFFFFFF)),
+    ]
+    datagrams, tables = [], []
+    for sp, n, inf in cases:
+        d = np.zeros(50, O.RESULT_DTYPE)
+        for k, (c, l, f, s) in enumerate(sp):
+            d[k] = (c.encode(), l.encode(), f, s)
+        info = O.ReportInfo(rcall=inf["rcall"].encode(), rloc=inf["rloc"].encode(), app_version=inf["app_version"].encode(),
+                            dial_freq=inf["dial_freq"], unixtime=inf["unixtime"], sequence=inf["sequence"], random_id=inf["random_id"])
+        sl = [dict(call=c, loc=l, freq=f, snr=s) for c, l, f, s in sp]
+        datagrams.append(dict(spots=sl, n_results=n, info=inf, hex=O.pskreporter_datagram(d, n, info).tobytes().hex()))
+        when = [2025, 2, 12, 7, 5]
+        tables.append(dict(spots=sl, n_results=n, dial_freq=inf["dial_freq"], when=when,
+                           text=O.format_spots(d, n, inf["dial_freq"], *when)))
+    json.dump({"generator": "oracle ft8o_pskreporter_datagram / ft8o_format_spots", "datagrams": datagrams, "tables": tables},
+              open(os.path.join(HERE, "report.json"), "w"), indent=1)
+    print("report golden written:", [len(c["hex"]) // 2 for c in datagrams])
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["report"]:
+        report_golden()
+    else:
+        main()

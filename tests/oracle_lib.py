@@ -237,3 +237,30 @@ def rx_capture(raw, normalise=False):
     n = C.c_uint32(0)
     L.ft8o_rx_capture(raw.ctypes.data, raw.size, i.ctypes.data, q.ctypes.data, C.byref(n), int(normalise))
     return i, q, n.value
+
+
+class ReportInfo(C.Structure):
+    _fields_ = [("rcall", C.c_char * 13), ("rloc", C.c_char * 7), ("app_version", C.c_char * 32),
+                ("dial_freq", C.c_uint32), ("unixtime", C.c_uint32), ("sequence", C.c_uint32),
+                ("random_id", C.c_uint32)]
+
+
+def pskreporter_datagram(decodes, n_results, info):
+    """postSpots() bytes (rtlsdr_ft8d.c:386-561) for one frame's spot list"""
+    decodes = np.ascontiguousarray(decodes)
+    assert decodes.dtype == RESULT_DTYPE
+    L = lib()
+    L.ft8o_pskreporter_datagram.argtypes = [C.c_void_p, C.c_int32, C.POINTER(ReportInfo), C.c_void_p]
+    out = np.zeros(1536, np.uint8)
+    n = L.ft8o_pskreporter_datagram(decodes.ctypes.data, int(n_results), C.byref(info), out.ctypes.data)
+    return out[:n].copy()
+
+
+def format_spots(decodes, n_results, dial_freq, year, month, mday, hour, minute):
+    decodes = np.ascontiguousarray(decodes)
+    L = lib()
+    L.ft8o_format_spots.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_size_t]
+    buf = C.create_string_buffer(4096)
+    L.ft8o_format_spots(decodes.ctypes.data, int(n_results), int(dial_freq), year, month, mday, hour, minute, buf, len(buf))
+    return buf.value.decode()
