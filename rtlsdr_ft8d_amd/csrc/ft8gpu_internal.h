@@ -26,9 +26,10 @@ constexpr int kScoresPerFrame = kSegments * kT0Count * kF0Count; // 35856
 constexpr int kLdpcN = 174, kLdpcK = 91, kLdpcM = 83;
 
 // waterfall kernel work decomposition
-constexpr int kWfRowsPerItem = 8;                              // FFT rows per work item
-constexpr int kWfItemsPerFrame = kRowsPerFrame / kWfRowsPerItem; // 23
-constexpr int kWfSpan = (kWfRowsPerItem - 1) * 256 + kNfft;    // 2816 samples staged per item
+constexpr int kWfRowsPerItem = 4;                              // FFT rows per work item
+constexpr int kWfGridPerCu = 12;                               // workgroups launched per CU (3 are resident, LDS-limited)
+constexpr int kWfItemsPerFrame = kRowsPerFrame / kWfRowsPerItem; // 46
+constexpr int kWfSpan = (kWfRowsPerItem - 1) * 256 + kNfft;    // samples staged per item
 
 struct Ft8Tables {                 // device-resident constant tables, built on the host at create()
     float  hann[kNfft];            // rtlsdr_ft8d.c:331-334 (sine window)

@@ -3,9 +3,10 @@
 //   rtlsdr_ft8d.c:1413-1433  |X|^2 -> 10*log10 -> (int)(2*dB+240) clamp -> uint8, OSR de-interleave
 //
 // Design (gfx950, wave64):
-//   * persistent workgroups of 4 waves; a work item is (frame, 8 consecutive FFT rows).  The
-//     2816-sample span those rows cover is read from HBM exactly once with 16-byte coalesced loads
-//     and staged in LDS (each sample feeds up to 4 overlapping rows: hop 256, length 1024).
+//   * workgroups of 4 waves walk lists of work items; an item is (frame, 4 consecutive FFT rows).
+//     The 1792-sample span those rows cover is read with 16-byte coalesced loads and staged in LDS
+//     (each sample feeds up to 4 overlapping rows: hop 256, length 1024); the 768 samples shared
+//     with the next item of the frame come from the XCD's L2 (see xcd_item).
 //   * one wave per FFT row, 16 complex points per lane.  1024 = 16 x 16 x 4: two radix-4 stages in
 //     registers, exchange through a padded (conflict-free) LDS buffer, two more radix-4 stages,
 //     second exchange, last radix-4 stage computing only the outputs that land in bins 0..511.
@@ -104,14 +105,14 @@ __device__ __forceinline__ unsigned quantise(float re, float im, const float *qt
 }
 
 constexpr int kXbuf = 1088;     // 1024 + 4 per 64 padding, complex entries per wave
-constexpr int kVecPerPlane = kWfSpan / 4;                 // 704 float4 per plane
+constexpr int kVecPerPlane = kWfSpan / 4;                 // float4 per plane
 constexpr int kPref = (2 * kVecPerPlane + 255) / 256;     // 6 float4 per thread (both planes)
 
 // XCD-aware work order.  The dispatcher places workgroup w on XCD w % 8 (each XCD has its own L2).
-// Consecutive chunks of a frame share 768 of their 2816 samples, so every XCD is given whole frames
+// Consecutive chunks of a frame share 768 of their samples, so every XCD is given whole frames
 // (frame f belongs to XCD f % 8) and its workgroups walk that XCD's chunks in order, which keeps the
 // overlap re-read inside one L2.  step = k-th item of this workgroup; returns the flat item index
-// frame * 23 + chunk, or -1 when the XCD has no more work.  (Placement affects cache traffic only.)
+// frame * kWfItemsPerFrame + chunk, or -1 when the XCD has no more work.  (Placement affects cache traffic only.)
 __device__ __forceinline__ int xcd_item(int step, int nframes) {
     const int xcd = blockIdx.x & 7, lw = blockIdx.x >> 3, wgs = gridDim.x >> 3;
     const int j = lw + wgs * step;                            // position in this XCD's chunk list
@@ -169,18 +170,22 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
 
     // software pipeline over work items: the next item's samples travel HBM -> registers while the
     // current item's rows are transformed, and are dropped into LDS at the top of the next round
-    static_assert(kPref == 6, "six named prefetch registers below");
+    static_assert((kPref == 6 && kWfRowsPerItem == 8) || (kPref == 4 && kWfRowsPerItem == 4), "named prefetch registers below");
     float4 p0, p1, p2, p3, p4, p5;
     p0 = p1 = p2 = p3 = p4 = p5 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool tail = tid + 256 * 5 < 2 * kVecPerPlane;       // the sixth vector exists for the first 128 threads only
+    const bool tail = tid + 256 * (kPref - 1) < 2 * kVecPerPlane;   // the last vector exists for the first 128 threads only
 #define FT8_PREFETCH(ITEM)                                           \
     do {                                                             \
         p0 = *item_vec(iq, (ITEM), tid);                             \
         p1 = *item_vec(iq, (ITEM), tid + 256);                       \
         p2 = *item_vec(iq, (ITEM), tid + 512);                       \
-        p3 = *item_vec(iq, (ITEM), tid + 768);                       \
-        p4 = *item_vec(iq, (ITEM), tid + 1024);                      \
-        if (tail) p5 = *item_vec(iq, (ITEM), tid + 1280);            \
+        if (kPref == 4) {                                            \
+            if (tail) p3 = *item_vec(iq, (ITEM), tid + 768);         \
+        } else {                                                     \
+            p3 = *item_vec(iq, (ITEM), tid + 768);                   \
+            p4 = *item_vec(iq, (ITEM), tid + 1024);                  \
+            if (tail) p5 = *item_vec(iq, (ITEM), tid + 1280);        \
+        }                                                            \
     } while (0)
     // item sequence of this workgroup: XCD-aware when the grid is a multiple of 8 workgroups, else strided
     int step = 0;
@@ -197,9 +202,13 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
             dst[tid] = p0;
             dst[tid + 256] = p1;
             dst[tid + 512] = p2;
-            dst[tid + 768] = p3;
-            dst[tid + 1024] = p4;
-            if (tail) dst[tid + 1280] = p5;
+            if (kPref == 4) {
+                if (tail) dst[tid + 768] = p3;
+            } else {
+                dst[tid + 768] = p3;
+                dst[tid + 1024] = p4;
+                if (tail) dst[tid + 1280] = p5;
+            }
         }
         __syncthreads();
         ++step;
@@ -268,7 +277,7 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
 hipError_t launch_waterfall(const float *iq, uint8_t *mag, const Ft8Tables *tab, int nframes,
                             int num_cus, hipStream_t s) {
     const int nitems = nframes * kWfItemsPerFrame;
-    int grid = num_cus * 2;                     // 2 workgroups per CU (LDS-limited), persistent
+    int grid = num_cus * kWfGridPerCu;           // workgroups per CU (LDS-limited), persistent
     if (grid > nitems) grid = nitems;
     if (grid < 1) return hipSuccess;
     // XCD-aware order needs whole groups of 8 workgroups and enough frames to give every XCD work

@@ -68,6 +68,49 @@ __global__ __launch_bounds__(256) void kdiv(float *out, float seed) {   // 8 ind
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// MODE 0: 16 independent v_rcp_f32; MODE 1: the same interleaved with 16 v_fma_f32 (do they overlap?)
+template <int MODE>
+__global__ __launch_bounds__(256) void krcp(float *out, float seed) {
+    float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    float b0 = a0 + 8, b1 = a0 + 9, b2 = a0 + 10, b3 = a0 + 11, b4 = a0 + 12, b5 = a0 + 13, b6 = a0 + 14, b7 = a0 + 15;
+    const float m = 0.999f, c = 0.001f;
+    for (int i = 0; i < N_ITERS; ++i) {
+        if (MODE == 0) {
+            asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n"
+                         "v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else {
+            asm volatile("v_rcp_f32 %0, %0\n v_fma_f32 %8, %8, %16, %17\n v_rcp_f32 %1, %1\n v_fma_f32 %9, %9, %16, %17\n"
+                         "v_rcp_f32 %2, %2\n v_fma_f32 %10, %10, %16, %17\n v_rcp_f32 %3, %3\n v_fma_f32 %11, %11, %16, %17\n"
+                         "v_rcp_f32 %4, %4\n v_fma_f32 %12, %12, %16, %17\n v_rcp_f32 %5, %5\n v_fma_f32 %13, %13, %16, %17\n"
+                         "v_rcp_f32 %6, %6\n v_fma_f32 %14, %14, %16, %17\n v_rcp_f32 %7, %7\n v_fma_f32 %15, %15, %16, %17\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7),
+                           "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7)
+                         : "v"(m), "v"(c));
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + b0 + b1 + b2 + b3 + b4 + b5 + b6 + b7;
+}
+
+// 16 independent integer / select ops of the kinds the BP loop uses besides the float arithmetic
+template <int MODE>
+__global__ __launch_bounds__(256) void kint(float *out, float seed) {
+    unsigned a[16];
+    for (int j = 0; j < 16; ++j) a[j] = (unsigned)(seed * 1000) + threadIdx.x * 7 + j;
+    const unsigned m = 0x7fffffffu;
+    for (int i = 0; i < N_ITERS; ++i) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (MODE == 0) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[j]) : "v"(m));
+            else if (MODE == 1) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(a[j]) : "v"(m));
+            else asm volatile("v_bfi_b32 %0, %1, %0, %0" : "+v"(a[j]) : "v"(m));
+        }
+    }
+    unsigned s = 0;
+    for (int j = 0; j < 16; ++j) s += a[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (float)s;
+}
+
 template <typename F>
 float time_ms(F f) {
     hipEvent_t a, b;
@@ -98,6 +141,16 @@ int main() {
     printf("v_pk_fma_f32  : %.3f ms  %.1f Gop/s(lane-instr)  %.1f TFLOP/s\n", t, lanes * N_ITERS * 8 / t / 1e6, lanes * N_ITERS * 16 * 2 / t / 1e9);
     t = time_ms([&] { hipLaunchKernelGGL(kdiv, dim3(blocks), dim3(threads), 0, 0, out, 1.0f); });
     printf("IEEE fdiv     : %.3f ms  %.1f Gdiv/s\n", t, lanes * (N_ITERS / 8) * 8 / t / 1e6);
+    t = time_ms([&] { hipLaunchKernelGGL(krcp<0>, dim3(blocks), dim3(threads), 0, 0, out, 1.0f); });
+    printf("v_rcp_f32     : %.3f ms  %.1f Gop/s(lane-instr)\n", t, lanes * N_ITERS * 8 / t / 1e6);
+    t = time_ms([&] { hipLaunchKernelGGL(krcp<1>, dim3(blocks), dim3(threads), 0, 0, out, 1.0f); });
+    printf("rcp+fma mixed : %.3f ms  (8 rcp + 8 fma per iteration)\n", t);
+    t = time_ms([&] { hipLaunchKernelGGL(kint<0>, dim3(blocks), dim3(threads), 0, 0, out, 1.0f); });
+    printf("v_min_u32     : %.3f ms  %.1f Gop/s(lane-instr)\n", t, lanes * N_ITERS * 16 / t / 1e6);
+    t = time_ms([&] { hipLaunchKernelGGL(kint<1>, dim3(blocks), dim3(threads), 0, 0, out, 1.0f); });
+    printf("v_lshl_add_u32: %.3f ms  %.1f Gop/s(lane-instr)\n", t, lanes * N_ITERS * 16 / t / 1e6);
+    t = time_ms([&] { hipLaunchKernelGGL(kint<2>, dim3(blocks), dim3(threads), 0, 0, out, 1.0f); });
+    printf("v_bfi_b32     : %.3f ms  %.1f Gop/s(lane-instr)\n", t, lanes * N_ITERS * 16 / t / 1e6);
     hipFree(out);
     return 0;
 }
