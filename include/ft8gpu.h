@@ -12,7 +12,9 @@
  *
  * Environment switches (read once): FT8GPU_DEVICE=<n> GPU used by the drop-in ft8_subsystem (default 0);
  * FT8GPU_OVERLAP=0 disables the two-half overlapped pipeline for batches >= 512 frames;
- * FT8GPU_FORCE_IEEE_DIV=1 makes the LDPC kernel use the compiler's IEEE division everywhere (test hook).
+ * FT8GPU_FORCE_IEEE_DIV=1 makes the LDPC kernel use the compiler's IEEE division everywhere (test hook);
+ * FT8GPU_DECODE_PIPELINE_FORM=1 makes ft8gpu_decode_candidates run the form of the LDPC kernel that
+ * ft8gpu_decode_batch uses (no exact error count: ldpc_errors is 0 or 83; test hook).
  */
 #ifndef FT8GPU_H
 #define FT8GPU_H

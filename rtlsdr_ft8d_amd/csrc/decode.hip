@@ -39,11 +39,20 @@ namespace {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+// The pipeline only needs to know WHETHER a hard decision satisfies all 83 checks (the error count
+// matters to nobody once it is non-zero).  The XOR of any set of parity rows is itself a parity
+// condition every codeword satisfies, so the rows are folded into kCheckGroups wave-uniform masks
+// that are tested on the scalar unit against the ballot words; only a word that passes all of them
+// (every codeword does; a non-codeword with e failed rows does so with probability ~2^-(groups-1)
+// when e is even and never when e is odd) goes through the exact per-row check on the vector unit.
+constexpr int kCheckGroups = 4;
+
 struct DecodeTables {
     uint16_t edge_slot[3][64][3];     // [r][lane][m_idx] -> float index of slot (m, pos) in the LDS tile
     uint64_t rowmask[2][64][3];       // [rr][lane][word] bit mask of the variables of check m = lane + 64 rr
     uint8_t  row_valid[2][64];
     uint8_t  row_seven[2][64];        // row has 7 members (else 6: slot 6 must stay 1.0f)
+    uint64_t group_mask[kCheckGroups][3];   // XOR of the row masks of check rows m with m % kCheckGroups == g
 };
 
 __device__ DecodeTables d_tab;
@@ -174,6 +183,12 @@ __device__ __forceinline__ void phase_atanh(const float (&P)[10], float (&ah)[9]
     }
 }
 
+// COUNT_ERRORS: ldpc_check() on every iteration with the exact number of failed rows (status
+// ldpc_errors = minimum seen, as ft8_lib's decode_status_t reports it).  Otherwise (the batch pipeline,
+// which consumes only ok / crc / text) the exact check runs only on words that pass the scalar group
+// test, and ldpc_errors is 0 for a codeword and 83 otherwise; the exit iteration and every other field
+// are the same in both forms.
+template <bool COUNT_ERRORS>
 __global__ __launch_bounds__(256)
 void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *__restrict__ cands,
                        const int32_t *__restrict__ counts, ft8gpu_decode_status *__restrict__ status,
@@ -252,6 +267,13 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int e = 0; e < 3; ++e) slot[3 * r + e] = d_tab.edge_slot[r][lane][e];
+    uint64_t gmask[kCheckGroups][3];
+    if (!COUNT_ERRORS) {
+#pragma unroll
+        for (int g = 0; g < kCheckGroups; ++g)
+#pragma unroll
+            for (int w = 0; w < 3; ++w) gmask[g][w] = d_tab.group_mask[g][w];      // wave-uniform: scalar loads
+    }
     uint64_t rmask[2][3];
     bool rvalid[2], rseven[2];
     int rowidx[2];
@@ -324,15 +346,30 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
         if ((B0 | B1 | B2) == 0ull) break;              // all-zero word is prohibited
 
         // ldpc_check
-        int errors = 0;
+        bool full_check = true;
+        if (!COUNT_ERRORS) {
+            uint32_t odd = 0;
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int par = (__popcll(B0 & rmask[rr][0]) + __popcll(B1 & rmask[rr][1]) + __popcll(B2 & rmask[rr][2])) & 1;
-            errors += __popcll(__ballot(rvalid[rr] && par));
+            for (int g = 0; g < kCheckGroups; ++g)
+                odd |= (uint32_t)__popcll((B0 & gmask[g][0]) ^ (B1 & gmask[g][1]) ^ (B2 & gmask[g][2]));
+            full_check = (odd & 1u) == 0;               // wave-uniform (ballot words and masks are scalars)
         }
-        if (errors < min_errors) {
-            min_errors = errors;
-            if (errors == 0) break;
+        if (full_check) {
+            int errors = 0;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int par = (__popcll(B0 & rmask[rr][0]) + __popcll(B1 & rmask[rr][1]) + __popcll(B2 & rmask[rr][2])) & 1;
+                errors += __popcll(__ballot(rvalid[rr] && par));
+            }
+            if (COUNT_ERRORS) {
+                if (errors < min_errors) {
+                    min_errors = errors;
+                    if (errors == 0) break;
+                }
+            } else if (errors == 0) {
+                min_errors = 0;
+                break;
+            }
         }
 
         // ---- bits -> checks ------------------------------------------------------------------
@@ -448,12 +485,19 @@ hipError_t decode_tables_init(hipStream_t s) {
                 h.rowmask[rr][l][n >> 6] |= 1ull << (n & 63);
             }
         }
+    for (int g = 0; g < kCheckGroups; ++g)
+        for (int w = 0; w < 3; ++w) h.group_mask[g][w] = 0;
+    for (int m = 0; m < kLdpcM; ++m)
+        for (int j = 0; j < kFT8_Num_rows[m]; ++j) {
+            const int n = kFT8_Nm[m][j] - 1;
+            h.group_mask[m % kCheckGroups][n >> 6] ^= 1ull << (n & 63);
+        }
     return hipMemcpyToSymbolAsync(HIP_SYMBOL(d_tab), &h, sizeof(h), 0, hipMemcpyHostToDevice, s);
 }
 
 hipError_t launch_decode(const uint8_t *mag, const ft8gpu_candidate *cands, const int32_t *counts,
                          ft8gpu_decode_status *status, int nframes, int max_candidates, int ldpc_iters,
-                         hipStream_t s) {
+                         bool count_errors, hipStream_t s) {
     // FT8GPU_FORCE_IEEE_DIV=1 routes every BP division through the compiler's IEEE expansion (the
     // path the guard falls back to); used by the parity tests to cover that path
     static const int force_ieee_div = [] { const char *e = getenv("FT8GPU_FORCE_IEEE_DIV"); return (e && e[0] == '1') ? 1 : 0; }();
@@ -462,7 +506,11 @@ hipError_t launch_decode(const uint8_t *mag, const ft8gpu_candidate *cands, cons
     const unsigned long long nblocks = (unsigned long long)nframes * bpf;
     if (nblocks * bpf >= (1ull << 32)) return hipErrorInvalidValue;           // keeps the multiply-high division exact
     const unsigned magic = (unsigned)((1ull << 32) / bpf) + 1u;
-    hipLaunchKernelGGL(ft8_decode_kernel, dim3((unsigned)nblocks), dim3(256), 0, s,
-                       mag, cands, counts, status, nframes, max_candidates, ldpc_iters, force_ieee_div, bpf, magic);
+    if (count_errors)
+        hipLaunchKernelGGL(ft8_decode_kernel<true>, dim3((unsigned)nblocks), dim3(256), 0, s,
+                           mag, cands, counts, status, nframes, max_candidates, ldpc_iters, force_ieee_div, bpf, magic);
+    else
+        hipLaunchKernelGGL(ft8_decode_kernel<false>, dim3((unsigned)nblocks), dim3(256), 0, s,
+                           mag, cands, counts, status, nframes, max_candidates, ldpc_iters, force_ieee_div, bpf, magic);
     return hipGetLastError();
 }

@@ -206,11 +206,11 @@ int run_pipeline_overlapped(ft8gpu_ctx *c, const float *d_iq, int n, struct deco
     // main stream: decode(H0), decode(H1), spots(H1)
     HIP_TRY(hipStreamWaitEvent(c->stream, E[2], 0));
     t.mark(3);
-    HIP_TRY(launch_decode(c->d_mag, c->d_cands, c->d_counts, c->d_status, n0, mc, p.ldpc_iters, c->stream));
+    HIP_TRY(launch_decode(c->d_mag, c->d_cands, c->d_counts, c->d_status, n0, mc, p.ldpc_iters, false, c->stream));
     t.mark(4);
     HIP_TRY(hipEventRecord(E[4], c->stream));
     HIP_TRY(hipStreamWaitEvent(c->stream, E[3], 0));
-    HIP_TRY(launch_decode(mag1, cands1, counts1, st1, n1, mc, p.ldpc_iters, c->stream));
+    HIP_TRY(launch_decode(mag1, cands1, counts1, st1, n1, mc, p.ldpc_iters, false, c->stream));
     t.mark(5);
     // side stream: spots(H0) while decode(H1) runs
     HIP_TRY(hipStreamWaitEvent(c->side, E[4], 0));
@@ -238,7 +238,7 @@ int run_pipeline(ft8gpu_ctx *c, const float *d_iq, int n, struct decoder_results
     t.mark(2);
     HIP_TRY(launch_heap(c->d_lists, c->d_list_counts, c->d_cands, c->d_counts, n, p.max_candidates, c->stream));
     t.mark(3);
-    HIP_TRY(launch_decode(c->d_mag, c->d_cands, c->d_counts, c->d_status, n, p.max_candidates, p.ldpc_iters, c->stream));
+    HIP_TRY(launch_decode(c->d_mag, c->d_cands, c->d_counts, c->d_status, n, p.max_candidates, p.ldpc_iters, false, c->stream));
     t.mark(4);
     HIP_TRY(launch_spots(c->d_cands, c->d_counts, c->d_status, n, p.max_candidates, p.min_score, d_dec, d_nres, c->stream));
     t.mark(5);
@@ -532,6 +532,9 @@ int ft8gpu_decode_candidates(ft8gpu_ctx *c, const uint8_t *mag, const ft8gpu_can
     if (nframes == 0) return 0;
     if (!mag || !cands || !counts || !status) return fail("NULL array argument");
     const int mc = c->params.max_candidates;
+    // the stage entry reports the exact ldpc_errors; FT8GPU_DECODE_PIPELINE_FORM=1 runs the form of the
+    // kernel the batch pipeline uses instead (test hook: every field but ldpc_errors must agree)
+    static const bool count_errors = [] { const char *e = getenv("FT8GPU_DECODE_PIPELINE_FORM"); return !(e && e[0] == '1'); }();
     for (int f0 = 0; f0 < nframes; f0 += c->max_frames) {
         const int n = (nframes - f0 < c->max_frames) ? nframes - f0 : c->max_frames;
         const bool dev = flags & FT8GPU_DEVICE_PTRS;
@@ -545,7 +548,7 @@ int ft8gpu_decode_candidates(ft8gpu_ctx *c, const uint8_t *mag, const ft8gpu_can
             HIP_TRY(hipMemcpyAsync(c->d_counts, counts + f0, n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipMemsetAsync(c->d_status, 0, (size_t)n * mc * sizeof(ft8gpu_decode_status), c->stream));
         }
-        HIP_TRY(launch_decode(dm, dc, dn, dst, n, mc, c->params.ldpc_iters, c->stream));
+        HIP_TRY(launch_decode(dm, dc, dn, dst, n, mc, c->params.ldpc_iters, count_errors, c->stream));
         if (!dev) {
             HIP_TRY(hipMemcpyAsync(status + (size_t)f0 * mc, dst, (size_t)n * mc * sizeof(ft8gpu_decode_status), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));

@@ -46,7 +46,7 @@ hipError_t launch_heap(const uint32_t *lists, const int32_t *list_counts, ft8gpu
                        int32_t *counts, int nframes, int max_candidates, hipStream_t s);
 hipError_t launch_decode(const uint8_t *mag, const ft8gpu_candidate *cands, const int32_t *counts,
                          ft8gpu_decode_status *status, int nframes, int max_candidates, int ldpc_iters,
-                         hipStream_t s);
+                         bool count_errors, hipStream_t s);
 hipError_t launch_spots(const ft8gpu_candidate *cands, const int32_t *counts,
                         const ft8gpu_decode_status *status, int nframes, int max_candidates,
                         int min_score, struct decoder_results *decodes, int32_t *n_results, hipStream_t s);

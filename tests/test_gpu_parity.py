@@ -393,6 +393,47 @@ print('BAD', bad, 'CANDS', int(counts.sum()))
     assert "BAD 0 CANDS" in out.stdout, out.stdout[-500:]
 
 
+def test_decode_pipeline_form_of_the_kernel(oracle):
+    """the batch pipeline runs the BP kernel without the exact error count: a scalar group-parity test
+    screens every hard decision and only survivors get the exact per-row check.  With
+    FT8GPU_DECODE_PIPELINE_FORM=1 the stage entry runs that form; every field except ldpc_errors must be
+    what the oracle (and the counting form) reports, and ldpc_errors must be 0 exactly for codewords."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import oracle_lib as O, synth_util as S, rtlsdr_ft8d_amd as ft8
+enc = S.oracle_encode_fn(O)
+frames = [np.stack(O.selftest_signal()), np.zeros((2, 48000), np.float32)]
+frames += [S.make_frame(s, n, enc, snr_range=(-20, 0), cq_fraction=0.7)[0] for s, n in [(21, 20), (22, 40), (23, 12), (24, 60), (25, 0)]]
+iq = np.stack(frames)
+bad = ncand = nok = 0
+for iters in (20, 3):
+    with ft8.Decoder(device=0, max_frames=iq.shape[0], ldpc_iters=iters) as d:
+        mag = d.waterfall(iq)
+        cands, counts = d.find_sync(mag)
+        st = d.decode_candidates(mag, cands, counts)
+    for k in range(iq.shape[0]):
+        for c in range(counts[k]):
+            r = O.decode(mag[k], cands[k, c:c + 1], iters)
+            g = st[k, c]
+            ncand += 1
+            nok += bool(g['ok'])
+            bad += not ((g['ldpc_errors'] == 0) == (r['ldpc_errors'] == 0) and g['ldpc_errors'] in (0, 83) and g['iters'] == r['iters']
+                        and bytes(g['a91']) == r['a91'] and bool(g['ok']) == r['ok']
+                        and (not r['ok'] or (g['text'].decode() == r['text'] and g['crc_extracted'] == r['crc_extracted'])))
+print('BAD', bad, 'CANDS', ncand, 'OK', nok)
+"""
+    env = dict(os.environ, FT8GPU_DECODE_PIPELINE_FORM="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "BAD 0 CANDS" in out.stdout, out.stdout[-500:]
+    assert int(out.stdout.split("OK")[1]) > 20
+
+
 def test_c_caller_self_test_and_file_replay(oracle, tmp_path):
     """examples/ft8_replay.c: a plain C program that links libft8gpu.so and uses only the reference's
     own three symbols (initFFTW / ft8_subsystem / freeFFTW) the way rtlsdr_ft8d.c does for -t and -r"""
