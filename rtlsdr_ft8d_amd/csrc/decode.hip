@@ -67,6 +67,12 @@ __host__ __device__ constexpr int slot_index(int m, int pos) {
 }
 
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+// a + b as one v_add_f32 the vectoriser cannot see through
+__device__ __forceinline__ float add_f32(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 // a / b, correctly rounded, for a pair; preconditions in the file header
 __device__ __forceinline__ f2 div_pair_fast(f2 a, f2 b) {
@@ -158,29 +164,6 @@ __device__ inline uint32_t crc14_82(const uint8_t *msg) {
         else rem = (rem << 1) & 0xFFFFu;
     }
     return rem & 0x3FFFu;
-}
-
-// bits -> checks: toc[m][n_idx] = fast_tanh(-Tnm / 2), Tnm = codeword[n] + (the other two tov, m_idx ascending)
-template <bool FAST>
-__device__ __forceinline__ void phase_tanh(const float (&x)[10], const int (&slot)[9], float *toc) {
-#pragma unroll
-    for (int p = 0; p < 5; ++p) {
-        const f2 t = tanh_pair<FAST>(f2{ x[2 * p], x[2 * p + 1] });
-        toc[slot[2 * p]] = t.x;
-        if (p < 4) toc[slot[2 * p + 1]] = t.y;
-    }
-}
-
-// checks -> bits: tov[n][m_idx] = -2 * fast_atanh(product of the other toc of the row).  The state kept
-// in registers is ah = fast_atanh(...) itself, i.e. tov = -2 * ah exactly (see "half domain" below).
-template <bool FAST>
-__device__ __forceinline__ void phase_atanh(const float (&P)[10], float (&ah)[9]) {
-#pragma unroll
-    for (int p = 0; p < 5; ++p) {
-        const f2 t = atanh_pair<FAST>(f2{ P[2 * p], P[2 * p + 1] });
-        ah[2 * p] = t.x;
-        if (p < 4) ah[2 * p + 1] = t.y;
-    }
 }
 
 // COUNT_ERRORS: ldpc_check() on every iteration with the exact number of failed rows (status
@@ -304,45 +287,66 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
     // hard decision (cw + tov0 + tov1 + tov2 > 0) is ((cwh + ah0) + ah1) + ah2 < 0.  fast_ok (all state
     // values 0 or >= 2^-59, see guard_key) guarantees the "nothing subnormal" premise; when it does
     // not hold the sums are formed in the reference's own domain from tov = -2*ah (an exact product).
-    float ah[9];
+    // Register layout of the nine edge states of a lane (variables r = 0,1,2; edges e = 0,1,2 of each):
+    //   A[r] = (ah[r][2], ah[r][1])   B = (ah[0][0], ah[1][0])   c2 = ah[2][0]
+    // chosen so that the sums below are packed adds on whole register pairs without any shuffling:
+    //   u_r = cwh_r + ah[r][0]                    (u_0, u_1) = cwh01 + B
+    //   X[r] = (x[r][1], x[r][2]) = u_r + A[r]    Tnm of edge 1 omits ah[r][1], of edge 2 omits ah[r][2]
+    //   x[r][0] = (cwh_r + ah[r][1]) + ah[r][2]   -> Y = (x[0][0], x[1][0]),  Z = (x[2][0], 0)
+    //   hard decision: (u_r + ah[r][1]) + ah[r][2] = X[r].y + A[r].x
+    // Which values share a register pair is free (every value is computed by the same operations in
+    // the same order whatever its neighbour is); the LDS slot of every edge is a per-lane constant.
+    f2 A[3], B = { 0.0f, 0.0f };
+    float c2 = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) ah[i] = 0.0f;
+    for (int r = 0; r < 3; ++r) A[r] = f2{ 0.0f, 0.0f };
     float cwh[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) cwh[r] = cw[r] * -0.5f;
+    const f2 cwh01 = { cwh[0], cwh[1] };
+    const uint64_t has2_mask = __ballot(has[2]);         // lanes that own a third variable (n = lane + 128 < 174)
     int min_errors = kLdpcM;
     uint64_t B0 = 0, B1 = 0, B2 = 0;
     int iter = 0;
     bool fast_ok = !force_ieee_div;     // every state value is 0 or >= 2^-59 (true for the initial zeros)
     for (; iter < max_iters; ++iter) {
         // hard decision (tov = 0 in iteration 0) and Tnm / x for the lane's nine edges
-        // (lanes without a third variable compute on zeros and write to the spare row)
-        bool bit[3];
-        float x[10];
+        // (lanes without a third variable compute on spare-row content and write to the spare row)
+        f2 X[3], Y, Z;
         if (fast_ok) {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const float u = cwh[r] + ah[3 * r];
-                bit[r] = has[r] && (((u + ah[3 * r + 1]) + ah[3 * r + 2]) < 0.0f);
-                x[3 * r + 0] = (cwh[r] + ah[3 * r + 1]) + ah[3 * r + 2];
-                x[3 * r + 1] = u + ah[3 * r + 2];
-                x[3 * r + 2] = u + ah[3 * r + 1];
-            }
+            const f2 u01 = cwh01 + B;
+            const float u2 = cwh[2] + c2;
+            X[0] = f2{ u01.x, u01.x } + A[0];
+            X[1] = f2{ u01.y, u01.y } + A[1];
+            X[2] = f2{ u2, u2 } + A[2];
+            // (scalar adds: written opaquely, otherwise the vectoriser pairs them up behind four v_mov)
+            Y.x = add_f32(add_f32(cwh[0], A[0].y), A[0].x);
+            Y.y = add_f32(add_f32(cwh[1], A[1].y), A[1].x);
+            Z.x = add_f32(add_f32(cwh[2], A[2].y), A[2].x);
+            B0 = __ballot((X[0].y + A[0].x) < 0.0f);               // lanes 0..63 all own variables 0..127
+            B1 = __ballot((X[1].y + A[1].x) < 0.0f);
+            B2 = __ballot((X[2].y + A[2].x) < 0.0f) & has2_mask;
         } else {
+            const float ah0[3] = { B.x, B.y, c2 };
+            float x0[3];
+            bool bit[3];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                const float v0 = -2 * ah[3 * r], v1 = -2 * ah[3 * r + 1], v2 = -2 * ah[3 * r + 2];   // tov
+                const float v0 = -2 * ah0[r], v1 = -2 * A[r].y, v2 = -2 * A[r].x;   // tov
                 const float u = cw[r] + v0;
                 bit[r] = has[r] && (((u + v1) + v2) > 0.0f);
-                x[3 * r + 0] = ((cw[r] + v1) + v2) * -0.5f;    // == -Tnm / 2 bit for bit (scaling by a power of two)
-                x[3 * r + 1] = (u + v2) * -0.5f;
-                x[3 * r + 2] = (u + v1) * -0.5f;
+                x0[r] = ((cw[r] + v1) + v2) * -0.5f;            // == -Tnm / 2 bit for bit (scaling by a power of two)
+                X[r].x = (u + v2) * -0.5f;
+                X[r].y = (u + v1) * -0.5f;
             }
+            Y.x = x0[0];
+            Y.y = x0[1];
+            Z.x = x0[2];
+            B0 = __ballot(bit[0]);
+            B1 = __ballot(bit[1]);
+            B2 = __ballot(bit[2]);
         }
-        x[9] = 0.0f;
-        B0 = __ballot(bit[0]);
-        B1 = __ballot(bit[1]);
-        B2 = __ballot(bit[2]);
+        Z.y = 0.0f;
         if ((B0 | B1 | B2) == 0ull) break;              // all-zero word is prohibited
 
         // ldpc_check
@@ -372,9 +376,29 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
             }
         }
 
-        // ---- bits -> checks ------------------------------------------------------------------
-        if (fast_ok) phase_tanh<true>(x, slot, toc);
-        else phase_tanh<false>(x, slot, toc);
+        // ---- bits -> checks: toc[m][n_idx] = fast_tanh(-Tnm / 2) -------------------------------
+        {
+            f2 t[5];
+            if (fast_ok) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) t[r] = tanh_pair<true>(X[r]);
+                t[3] = tanh_pair<true>(Y);
+                t[4] = tanh_pair<true>(Z);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) t[r] = tanh_pair<false>(X[r]);
+                t[3] = tanh_pair<false>(Y);
+                t[4] = tanh_pair<false>(Z);
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                toc[slot[3 * r + 1]] = t[r].x;
+                toc[slot[3 * r + 2]] = t[r].y;
+            }
+            toc[slot[0]] = t[3].x;
+            toc[slot[3]] = t[3].y;
+            toc[slot[6]] = t[4].x;
+        }
         wave_lds_sync();
 
         // ---- check rows: ordered products that skip one member, for all members ---------------
@@ -397,19 +421,36 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
         }
         wave_lds_sync();
 
-        // ---- checks -> bits ------------------------------------------------------------------
-        float P[10];
-        uint32_t gmin = 0xFFFFFFFFu;
+        // ---- checks -> bits: tov[n][m_idx] = -2 * fast_atanh(product of the other toc of the row); the
+        // state kept is fast_atanh(...) itself, i.e. tov = -2 * state exactly (half domain) -------------
+        f2 PA[3], PB, PC;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const float v = toc[slot[i]];
-            P[i] = (i < 6 || has[2]) ? v : 0.0f;                 // idle lanes: zeros, so they never trip the guard
-            gmin = min(gmin, guard_key(P[i]));
-        }
-        P[9] = 0.0f;
+        for (int r = 0; r < 2; ++r) PA[r] = f2{ toc[slot[3 * r + 2]], toc[slot[3 * r + 1]] };
+        PB = f2{ toc[slot[0]], toc[slot[3]] };
+        PA[2] = f2{ toc[slot[8]], toc[slot[7]] };
+        PC = f2{ toc[slot[6]], 0.0f };
+        // Lanes without a third variable run these three edges on whatever the spare row holds; nothing
+        // they compute leaves the spare row or their own registers (their decision bit is masked), so the
+        // guard ignores them.
+        uint32_t g2 = min(guard_key(PC.x), min(guard_key(PA[2].x), guard_key(PA[2].y)));
+        g2 = has[2] ? g2 : 0xFFFFFFFFu;
+        uint32_t gmin = min(g2, min(guard_key(PB.x), guard_key(PB.y)));
+#pragma unroll
+        for (int r = 0; r < 2; ++r) gmin = min(gmin, min(guard_key(PA[r].x), guard_key(PA[r].y)));
         fast_ok = __all(gmin >= kGuardMin) && !force_ieee_div;       // wave-uniform; also governs the next tanh phase
-        if (fast_ok) phase_atanh<true>(P, ah);
-        else phase_atanh<false>(P, ah);
+        f2 C;
+        if (fast_ok) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) A[r] = atanh_pair<true>(PA[r]);
+            B = atanh_pair<true>(PB);
+            C = atanh_pair<true>(PC);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) A[r] = atanh_pair<false>(PA[r]);
+            B = atanh_pair<false>(PB);
+            C = atanh_pair<false>(PC);
+        }
+        c2 = C.x;
         // (the next iteration's toc stores hit only this lane's own slots; LDS is in order per wave)
     }
 
