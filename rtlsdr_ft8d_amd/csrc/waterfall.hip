@@ -105,8 +105,8 @@ __device__ __forceinline__ unsigned quantise(float re, float im, const float *qt
 }
 
 constexpr int kXbuf = 1088;     // 1024 + 4 per 64 padding, complex entries per wave
-constexpr int kVecPerPlane = kWfSpan / 4;                 // float4 per plane
-constexpr int kPref = (2 * kVecPerPlane + 255) / 256;     // 6 float4 per thread (both planes)
+constexpr int kVecPerPlane = kWfSpan / 4;                 // float4 per plane of a work item's span
+static_assert(kVecPerPlane > 256 && kVecPerPlane <= 512, "two I and two Q vectors per thread (the second pair for part of the workgroup)");
 
 // XCD-aware work order.  The dispatcher places workgroup w on XCD w % 8 (each XCD has its own L2).
 // Consecutive chunks of a frame share 768 of their samples, so every XCD is given whole frames
@@ -121,19 +121,18 @@ __device__ __forceinline__ int xcd_item(int step, int nframes) {
     return frame < nframes ? frame * kWfItemsPerFrame + chunk : -1;
 }
 
-// address of the i-th float4 of a work item's staged span (I plane first, then Q plane)
-__device__ __forceinline__ const float4 *item_vec(const float *__restrict__ iq, int item, int i) {
+// address of the i-th float4 of one plane (0 = I, 1 = Q) of a work item's span
+__device__ __forceinline__ const float4 *item_vec(const float *__restrict__ iq, int item, int plane, int i) {
     const int frame = item / kWfItemsPerFrame;
     const int chunk = item - frame * kWfItemsPerFrame;
     const float *base = iq + (size_t)frame * (2 * kNSamples) + chunk * (kWfRowsPerItem * 256);
-    const int plane = i >= kVecPerPlane ? 1 : 0;
-    return reinterpret_cast<const float4 *>(base + plane * kNSamples) + (i - plane * kVecPerPlane);
+    return reinterpret_cast<const float4 *>(base + plane * kNSamples) + i;
 }
 
 __global__ __launch_bounds__(256)
 void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ mag,
                           const Ft8Tables *__restrict__ tab, int nitems, int nframes, int xcd_order) {
-    __shared__ __attribute__((aligned(16))) float s_in[2][kWfSpan];          // staged I and Q
+    __shared__ __attribute__((aligned(16))) float2 s_in[kWfSpan];            // staged samples, (I, Q) interleaved
     __shared__ __attribute__((aligned(16))) float2 s_x[4][kXbuf];            // per-wave exchange
     __shared__ __attribute__((aligned(16))) float s_thr[260];
     __shared__ __attribute__((aligned(16))) unsigned char s_out[4][512];
@@ -169,22 +168,19 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
     unsigned char *ob = s_out[wave];
 
     // software pipeline over work items: the next item's samples travel HBM -> registers while the
-    // current item's rows are transformed, and are dropped into LDS at the top of the next round
-    static_assert((kPref == 6 && kWfRowsPerItem == 8) || (kPref == 4 && kWfRowsPerItem == 4), "named prefetch registers below");
-    float4 p0, p1, p2, p3, p4, p5;
-    p0 = p1 = p2 = p3 = p4 = p5 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool tail = tid + 256 * (kPref - 1) < 2 * kVecPerPlane;   // the last vector exists for the first 128 threads only
+    // current item's rows are transformed, and are dropped into LDS at the top of the next round.
+    // A thread fetches the same four samples of both planes, so it can store them as (I, Q) pairs:
+    // the row loads below are then single 8-byte reads that land in a register pair as a complex value.
+    float4 pI0, pQ0, pI1, pQ1;
+    pI0 = pQ0 = pI1 = pQ1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool tail = tid + 256 < kVecPerPlane;               // the second pair exists for part of the workgroup only
 #define FT8_PREFETCH(ITEM)                                           \
     do {                                                             \
-        p0 = *item_vec(iq, (ITEM), tid);                             \
-        p1 = *item_vec(iq, (ITEM), tid + 256);                       \
-        p2 = *item_vec(iq, (ITEM), tid + 512);                       \
-        if (kPref == 4) {                                            \
-            if (tail) p3 = *item_vec(iq, (ITEM), tid + 768);         \
-        } else {                                                     \
-            p3 = *item_vec(iq, (ITEM), tid + 768);                   \
-            p4 = *item_vec(iq, (ITEM), tid + 1024);                  \
-            if (tail) p5 = *item_vec(iq, (ITEM), tid + 1280);        \
+        pI0 = *item_vec(iq, (ITEM), 0, tid);                         \
+        pQ0 = *item_vec(iq, (ITEM), 1, tid);                         \
+        if (tail) {                                                  \
+            pI1 = *item_vec(iq, (ITEM), 0, tid + 256);               \
+            pQ1 = *item_vec(iq, (ITEM), 1, tid + 256);               \
         }                                                            \
     } while (0)
     // item sequence of this workgroup: XCD-aware when the grid is a multiple of 8 workgroups, else strided
@@ -198,16 +194,12 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
 
         __syncthreads();                        // previous item's readers are done with s_in
         {
-            float4 *dst = reinterpret_cast<float4 *>(&s_in[0][0]);      // s_in[1] follows s_in[0]
-            dst[tid] = p0;
-            dst[tid + 256] = p1;
-            dst[tid + 512] = p2;
-            if (kPref == 4) {
-                if (tail) dst[tid + 768] = p3;
-            } else {
-                dst[tid + 768] = p3;
-                dst[tid + 1024] = p4;
-                if (tail) dst[tid + 1280] = p5;
+            float4 *dst = reinterpret_cast<float4 *>(s_in);             // float4 = two (I, Q) pairs
+            dst[2 * tid]     = make_float4(pI0.x, pQ0.x, pI0.y, pQ0.y);
+            dst[2 * tid + 1] = make_float4(pI0.z, pQ0.z, pI0.w, pQ0.w);
+            if (tail) {
+                dst[2 * (tid + 256)]     = make_float4(pI1.x, pQ1.x, pI1.y, pQ1.y);
+                dst[2 * (tid + 256) + 1] = make_float4(pI1.z, pQ1.z, pI1.w, pQ1.w);
             }
         }
         __syncthreads();
@@ -220,13 +212,14 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
 #pragma unroll 1
         for (int rr = 0; rr < kWfRowsPerItem / 4; ++rr) {
             const int row_in_item = wave * (kWfRowsPerItem / 4) + rr;
-            const float *sI = s_in[0] + row_in_item * 256;
-            const float *sQ = s_in[1] + row_in_item * 256;
+            const float2 *sIQ = s_in + row_in_item * 256;
 
             c32 x[16];
 #pragma unroll
-            for (int a = 0; a < 16; ++a)        // rtlsdr_ft8d.c:1407-1410
-                x[a] = c32{ sI[lane + 64 * a], sQ[lane + 64 * a] } * c32{ hw[a], hw[a] };
+            for (int a = 0; a < 16; ++a) {      // rtlsdr_ft8d.c:1407-1410
+                const float2 v = sIQ[lane + 64 * a];
+                x[a] = c32{ v.x, v.y } * c32{ hw[a], hw[a] };
+            }
             pass16(x, twA1, twB1);              // stages 0, 1
 #pragma unroll
             for (int a = 0; a < 16; ++a) xb[pad_idx(lane + 64 * a)] = make_float2(x[a].x, x[a].y);
