@@ -39,28 +39,50 @@ constexpr int kSyncLds = kOffS + kNumBlocks * kSPitch * 2 + kGuardS;   // 79104 
 //   K = 6 (last of a Costas block) has no look-ahead:     S5 - [b<91](p-p[b+1][f])
 //   K = 3 (tone 0) has no lower bin:                      S5 - [f>0](p-p[f-1])
 // so every symbol is one S5 read, three of them with a two-byte correction.  pb / sb point at
-// (row t0, column f0) of P / S5; everything that depends on b is a wave-uniform 0/1 weight.
-template <int K, int C>
-__device__ __forceinline__ int sync_symbol(const uint8_t *pb, const int16_t *sb, int t0, bool f_gt0) {
+// (row t0, column f0) of P / S5.  The byte left of column 0 of every row is a copy of column 0
+// (see the kernel), so the K = 3 correction needs no test for f = 0.
+//
+// Everything that depends on b is a wave-uniform 0/1 weight, and at most one of the three Costas
+// blocks of a position can touch the edge of the waterfall.  MODE names it, so that the other two
+// (or, for the interior time offsets, all three) are plain sums without weights:
+//   MODE 0: 1 <= t0 <= 12, every block and every time neighbour exists
+//   MODE 1: t0 <= 0, Costas block m = 0 is weighted          MODE 2: t0 >= 13, block m = 2 is weighted
+template <int K, int C, int MODE>
+__device__ __forceinline__ int sync_symbol(const uint8_t *pb, const int16_t *sb, int t0) {
     int acc = 0;
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         const int rel = 36 * m + K;                                      // compile-time row offset from t0
-        const int b = t0 + rel;                                          // wave-uniform
-        const int w = (b >= 0 && b < kNumBlocks) ? 1 : 0;
-        acc += w * (int)sb[rel * kSPitch + C];
-        if (K == 0) {
-            const int wm = (w && b > 0) ? 1 : 0;
-            acc -= wm * ((int)pb[rel * kPitch + C] - (int)pb[(rel - 1) * kPitch + C]);
-        } else if (K == 6) {
-            const int wp = (w && b + 1 < kNumBlocks) ? 1 : 0;
-            acc -= wp * ((int)pb[rel * kPitch + C] - (int)pb[(rel + 1) * kPitch + C]);
-        } else if (K == 3) {
-            const int d = (int)pb[rel * kPitch + C] - (int)pb[rel * kPitch + C - 1];
-            acc -= w * (f_gt0 ? d : 0);                                  // C == 0: the lower bin exists for f0 > 0 only
+        const bool weighted = (MODE == 1 && m == 0) || (MODE == 2 && m == 2);
+        if (!weighted) {
+            acc += (int)sb[rel * kSPitch + C];
+            if (K == 0) acc -= (int)pb[rel * kPitch + C] - (int)pb[(rel - 1) * kPitch + C];
+            else if (K == 6) acc -= (int)pb[rel * kPitch + C] - (int)pb[(rel + 1) * kPitch + C];
+            else if (K == 3) acc -= (int)pb[rel * kPitch + C] - (int)pb[rel * kPitch + C - 1];
+        } else {
+            const int b = t0 + rel;                                      // wave-uniform
+            const int w = (b >= 0 && b < kNumBlocks) ? 1 : 0;
+            acc += w * (int)sb[rel * kSPitch + C];
+            if (K == 0) {
+                const int wm = (w && b > 0) ? 1 : 0;
+                acc -= wm * ((int)pb[rel * kPitch + C] - (int)pb[(rel - 1) * kPitch + C]);
+            } else if (K == 6) {
+                const int wp = (w && b + 1 < kNumBlocks) ? 1 : 0;
+                acc -= wp * ((int)pb[rel * kPitch + C] - (int)pb[(rel + 1) * kPitch + C]);
+            } else if (K == 3) {
+                acc -= w * ((int)pb[rel * kPitch + C] - (int)pb[rel * kPitch + C - 1]);
+            }
         }
     }
     return acc;
+}
+
+// ft8_sync_score() numerator for one position; Costas pattern {3,1,4,0,6,5,2}
+template <int MODE>
+__device__ __forceinline__ int sync_sum(const uint8_t *pb, const int16_t *sb, int t0) {
+    return sync_symbol<0, 3, MODE>(pb, sb, t0) + sync_symbol<1, 1, MODE>(pb, sb, t0) + sync_symbol<2, 4, MODE>(pb, sb, t0) +
+           sync_symbol<3, 0, MODE>(pb, sb, t0) + sync_symbol<4, 6, MODE>(pb, sb, t0) + sync_symbol<5, 5, MODE>(pb, sb, t0) +
+           sync_symbol<6, 2, MODE>(pb, sb, t0);
 }
 
 // number of neighbour terms ft8_sync_score() averages over, for time offset t0 (independent of f0)
@@ -125,6 +147,11 @@ void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lis
         *reinterpret_cast<uint2 *>(s_s5 + row * kSPitch + col) = packed;
     }
     __syncthreads();
+    // The map is built; column 255 of P is not read again (f0 + tone <= 254), so the byte left of every
+    // row's column 0 (= column 255 of the row above, or the last guard byte) can take a copy of column 0:
+    // p[f] - p[f-1] is then 0 at f = 0, which is the reference's "no lower bin" case.
+    if (tid < kNumBlocks) s_wf[tid * kPitch - 1] = s_wf[tid * kPitch];
+    __syncthreads();
 
     const int sub = seg * kSyncWaves + wave;
     uint32_t *my_list = lists + ((size_t)frame * kSublistsPerFrame + sub) * kSublistCap;
@@ -146,11 +173,10 @@ void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lis
             const int fc = valid ? f0 : 0;
             const uint8_t *pb = s_wf + t0 * kPitch + fc;
             const int16_t *sb = s_s5 + t0 * kSPitch + fc;
-            // Costas pattern {3,1,4,0,6,5,2}
-            const bool f_gt0 = fc > 0;
-            int score = sync_symbol<0, 3>(pb, sb, t0, f_gt0) + sync_symbol<1, 1>(pb, sb, t0, f_gt0) + sync_symbol<2, 4>(pb, sb, t0, f_gt0) +
-                        sync_symbol<3, 0>(pb, sb, t0, f_gt0) + sync_symbol<4, 6>(pb, sb, t0, f_gt0) + sync_symbol<5, 5>(pb, sb, t0, f_gt0) +
-                        sync_symbol<6, 2>(pb, sb, t0, f_gt0);
+            int score;                                  // t0 is wave-uniform: one of three straight-line variants
+            if (t0 >= 1 && t0 <= 12) score = sync_sum<0>(pb, sb, t0);
+            else if (t0 <= 0) score = sync_sum<1>(pb, sb, t0);
+            else score = sync_sum<2>(pb, sb, t0);
             {
                 const float fs_ = (float)score;
                 score = (int)(fs_ * rnavg + __builtin_copysignf(0.004f, fs_));
