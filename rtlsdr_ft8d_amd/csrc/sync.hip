@@ -2,13 +2,13 @@
 // call site rtlsdr_ft8d.c:1450 (waterfall descriptor rtlsdr_ft8d.c:1440-1448).
 //
 // Two kernels:
-//   ft8_sync_kernel  one workgroup per (frame, time_sub, freq_sub): stages that 92x256-byte slice
-//                    of the waterfall in LDS, derives a 5-point-stencil int16 map from it (every
-//                    sync symbol is then one map read, 9 of the 21 with a two-byte correction), scores all
-//                    36 x 249 (time_offset, freq_offset) positions with the integer Costas
-//                    neighbour-contrast score, and compacts the positions with score >= min_score,
-//                    in the reference's scan order, with __ballot/popcount prefix sums (no atomics,
-//                    no barriers after the map is built).
+//   ft8_sync_kernel  one workgroup per (frame, time_sub, freq_sub).  ft8_sync_score() sums, over three
+//                    Costas blocks m and seven symbols k, neighbour contrasts of the waterfall at block
+//                    b = t0 + 36 m + k.  Which terms exist depends on b and k only, never on the
+//                    frequency, so the sum over m is taken ONCE per (t0 + k) while the slice streams
+//                    through registers ("collapsed maps" in LDS), and a position's score is seven int16
+//                    reads and six adds.  Positions with score >= min_score are compacted in the
+//                    reference's scan order with __ballot/popcount prefix sums (no atomics).
 //   ft8_heap_kernel  replays the reference's bounded min-heap (strict '>' replacement, its
 //                    heapify tie rules and the final heap sort) over the compacted list, one
 //                    wave per frame with the heap in LDS, so that candidate order is bit-identical
@@ -17,72 +17,31 @@
 
 namespace {
 
-// LDS layout of one (frame, time_sub, freq_sub) slice, in this order, one allocation:
-//   guard (13 rows of bytes) | P: uint8 [92][256] waterfall slice | S5: int16 [92][256] stencil map | guard (10 int16 rows)
-// A sync symbol at an out-of-range block (b < 0 or b >= 92) is addressed like any other, lands in a
-// guard or in the neighbouring map, and is multiplied by a wave-uniform weight of 0 -- so every LDS
-// read of a position has a compile-time offset from one base register and no address arithmetic.
-constexpr int kPitch = 256;                              // bytes per waterfall row
-constexpr int kSPitch = 256;                             // int16 per stencil row
-constexpr int kGuardP = 13 * kPitch;                     // rows -13..-1 (b - 1 for b = t0 = -12)
-constexpr int kOffP = kGuardP;
-constexpr int kOffS = kOffP + kNumBlocks * kPitch;       // byte offset of S5
-constexpr int kGuardS = 10 * kSPitch * 2;
-constexpr int kSyncLds = kOffS + kNumBlocks * kSPitch * 2 + kGuardS;   // 79104 bytes: two workgroups per CU
+// For a block b and column f of the (time_sub, freq_sub) slice p[92][256]:
+//   dl = [f>0](p - p[f-1])   dr = p - p[f+1]   du = [b>0](p - p[b-1])   dd = [b<91](p - p[b+1])
+// A sync symbol k at block b contributes (Costas tones are 0..6, so the upper bin always exists):
+//   k in {1,2,4,5}:  dl + dr + du + dd          k = 0 (no look-back inside a Costas block):  dl + dr + dd
+//   k = 6 (no look-ahead):  dl + dr + du         k = 3 (tone 0 has no lower bin):             dr + du + dd
+// and nothing when b is outside [0, 92).  With t' = t0 + k the block is b = t' + 36 m, hence
+//   score numerator(t0, f0) = M0[t0][f0+3] + MA[t0+1][f0+1] + MA[t0+2][f0+4] + M3[t0+3][f0]
+//                           + MA[t0+4][f0+6] + MA[t0+5][f0+5] + M6[t0+6][f0+2]          (pattern 3,1,4,0,6,5,2)
+// where each map is the sum of its symbol's contribution over the (up to three) m with b in range:
+//   MA[t'] for t' in [-11, 29)   M0[t'] for t' in [-12, 24)   M3[t'] for t' in [-9, 27)   M6[t'] for t' in [-6, 30)
+// Magnitudes: |cell| <= 3 * 4 * 255 = 3060, so int16 holds a cell and packed 16-bit arithmetic is exact.
+constexpr int kMapPitch = 256;                            // int16 per map row
+constexpr int kRowsA = 40, kRowsK = 36;                   // rows of MA / of M0, M3, M6
+constexpr int kOffA = 0, kOff0 = kRowsA, kOff3 = kRowsA + kRowsK, kOff6 = kRowsA + 2 * kRowsK;
+constexpr int kMapRows = kRowsA + 3 * kRowsK;             // 148 rows
+constexpr int kSyncLds = kMapRows * kMapPitch * 2;        // 75776 bytes: two workgroups per CU
+constexpr int kTqCount = 42;                              // t' = tq - 12 for tq in [0, 42)
 
-// Contribution of one sync symbol (Costas index K, tone column C) of ft8_sync_score() at absolute
-// block b = t0 + 36 m + K (wave-uniform) and bin column f = f0 + C.  The 5-point stencil map
-//   S5[b][f] = [f>0](p-p[f-1]) + (p-p[f+1]) + [b>0](p-p[b-1][f]) + [b<91](p-p[b+1][f])
-// already omits a missing time neighbour at the first/last block exactly as the reference does, and
-// for K in {1,2,4,5} it IS the symbol's contribution.  The other three symbols lack one term:
-//   K = 0 (first of a Costas block) has no look-back:    S5 - [b>0](p-p[b-1][f])
-//   K = 6 (last of a Costas block) has no look-ahead:     S5 - [b<91](p-p[b+1][f])
-//   K = 3 (tone 0) has no lower bin:                      S5 - [f>0](p-p[f-1])
-// so every symbol is one S5 read, three of them with a two-byte correction.  pb / sb point at
-// (row t0, column f0) of P / S5.  The byte left of column 0 of every row is a copy of column 0
-// (see the kernel), so the K = 3 correction needs no test for f = 0.
-//
-// Everything that depends on b is a wave-uniform 0/1 weight, and at most one of the three Costas
-// blocks of a position can touch the edge of the waterfall.  MODE names it, so that the other two
-// (or, for the interior time offsets, all three) are plain sums without weights:
-//   MODE 0: 1 <= t0 <= 12, every block and every time neighbour exists
-//   MODE 1: t0 <= 0, Costas block m = 0 is weighted          MODE 2: t0 >= 13, block m = 2 is weighted
-template <int K, int C, int MODE>
-__device__ __forceinline__ int sync_symbol(const uint8_t *pb, const int16_t *sb, int t0) {
-    int acc = 0;
-#pragma unroll
-    for (int m = 0; m < 3; ++m) {
-        const int rel = 36 * m + K;                                      // compile-time row offset from t0
-        const bool weighted = (MODE == 1 && m == 0) || (MODE == 2 && m == 2);
-        if (!weighted) {
-            acc += (int)sb[rel * kSPitch + C];
-            if (K == 0) acc -= (int)pb[rel * kPitch + C] - (int)pb[(rel - 1) * kPitch + C];
-            else if (K == 6) acc -= (int)pb[rel * kPitch + C] - (int)pb[(rel + 1) * kPitch + C];
-            else if (K == 3) acc -= (int)pb[rel * kPitch + C] - (int)pb[rel * kPitch + C - 1];
-        } else {
-            const int b = t0 + rel;                                      // wave-uniform
-            const int w = (b >= 0 && b < kNumBlocks) ? 1 : 0;
-            acc += w * (int)sb[rel * kSPitch + C];
-            if (K == 0) {
-                const int wm = (w && b > 0) ? 1 : 0;
-                acc -= wm * ((int)pb[rel * kPitch + C] - (int)pb[(rel - 1) * kPitch + C]);
-            } else if (K == 6) {
-                const int wp = (w && b + 1 < kNumBlocks) ? 1 : 0;
-                acc -= wp * ((int)pb[rel * kPitch + C] - (int)pb[(rel + 1) * kPitch + C]);
-            } else if (K == 3) {
-                acc -= w * ((int)pb[rel * kPitch + C] - (int)pb[rel * kPitch + C - 1]);
-            }
-        }
-    }
-    return acc;
-}
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 
-// ft8_sync_score() numerator for one position; Costas pattern {3,1,4,0,6,5,2}
-template <int MODE>
-__device__ __forceinline__ int sync_sum(const uint8_t *pb, const int16_t *sb, int t0) {
-    return sync_symbol<0, 3, MODE>(pb, sb, t0) + sync_symbol<1, 1, MODE>(pb, sb, t0) + sync_symbol<2, 4, MODE>(pb, sb, t0) +
-           sync_symbol<3, 0, MODE>(pb, sb, t0) + sync_symbol<4, 6, MODE>(pb, sb, t0) + sync_symbol<5, 5, MODE>(pb, sb, t0) +
-           sync_symbol<6, 2, MODE>(pb, sb, t0);
+// two waterfall bytes -> two zero-extended 16-bit lanes (v_perm_b32; selector bytes 0..3 pick from
+// `lo`, 4..7 from `hi`, 0x0c yields 0)
+__device__ __forceinline__ s16x2 bytes2(uint32_t hi, uint32_t lo, uint32_t selector) {
+    const uint32_t v = __builtin_amdgcn_perm(hi, lo, selector);
+    return __builtin_bit_cast(s16x2, v);
 }
 
 // number of neighbour terms ft8_sync_score() averages over, for time offset t0 (independent of f0)
@@ -103,56 +62,75 @@ __device__ __forceinline__ int sync_navg(int t0) {
 __global__ __launch_bounds__(64 * kSyncWaves)
 void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lists,
                      int32_t *__restrict__ list_counts, int16_t *__restrict__ score_map, int min_score) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_lds[kSyncLds];
-    uint8_t *s_wf = s_lds + kOffP;
-    int16_t *s_s5 = reinterpret_cast<int16_t *>(s_lds + kOffS);
+    __shared__ __attribute__((aligned(16))) int16_t s_map[kMapRows * kMapPitch];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: keep it in an SGPR
     const int frame = blockIdx.x >> 2, seg = blockIdx.x & 3;
     const int ts = seg >> 1, fs = seg & 1;
 
-    // mag[block][time_sub][freq_sub][bin]: one 256-byte run per block for this (ts, fs)
-    const uint8_t *src = mag + (size_t)frame * kMagArray + ts * 512 + fs * 256;
-    for (int i = tid; i < kNumBlocks * 16; i += 64 * kSyncWaves) {
-        const int row = i >> 4, col = (i & 15) * 16;
-        *reinterpret_cast<uint4 *>(s_wf + row * kPitch + col) =
-            *reinterpret_cast<const uint4 *>(src + (size_t)row * kBlockStride + col);
-    }
-    __syncthreads();
-    // 5-point stencil map, four cells per thread from dword reads; column 0 has no lower bin,
-    // column 255 is never addressed (f0 + tone <= 254) and is left 0
-    for (int i = tid; i < kNumBlocks * 64; i += 64 * kSyncWaves) {
-        const int row = i >> 6, col = (i & 63) * 4;
-        const uint8_t *p = s_wf + row * kPitch + col;
-        const uint32_t mid = *reinterpret_cast<const uint32_t *>(p);
-        const uint32_t up = row > 0 ? *reinterpret_cast<const uint32_t *>(p - kPitch) : mid;              // missing neighbour:
-        const uint32_t dn = row + 1 < kNumBlocks ? *reinterpret_cast<const uint32_t *>(p + kPitch) : mid;  // p - p = 0
-        const int left = col > 0 ? p[-1] : (int)(mid & 0xFF) /* p - p = 0: no lower bin */, right = col + 4 < 256 ? p[4] : 0;
-        int c[6];
-        c[0] = left;
+    // ---- build the collapsed maps ------------------------------------------------------------------
+    // mag[block][time_sub][freq_sub][bin]: one 256-byte run per block for this (ts, fs); lane = column
+    // group (4 bins).  A wave owns consecutive t' and slides a three-row window (b-1, b, b+1) per Costas
+    // block m down the slice, so every row is fetched once per wave that needs it, straight from global
+    // memory / L2 (the slice never sits in LDS).
+    {
+        const uint32_t *rows = reinterpret_cast<const uint32_t *>(mag + (size_t)frame * kMagArray + ts * 512 + fs * 256) + lane;
+        auto fetch = [&](int b) -> uint32_t {           // b is wave-uniform
+            return (b >= 0 && b < kNumBlocks) ? rows[(size_t)b * (kBlockStride / 4)] : 0u;
+        };
+        const int tq_begin = (wave * kTqCount) / kSyncWaves, tq_end = ((wave + 1) * kTqCount) / kSyncWaves;
+        uint32_t prev[3], cur[3], next[3];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) c[j + 1] = (mid >> (8 * j)) & 0xFF;
-        c[5] = right;
-        int v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int cc = c[j + 1];
-            v[j] = (cc - c[j]) + (cc - c[j + 2]) + (cc - (int)((up >> (8 * j)) & 0xFF)) + (cc - (int)((dn >> (8 * j)) & 0xFF));
+        for (int m = 0; m < 3; ++m) {
+            prev[m] = fetch(tq_begin - 12 + 36 * m - 1);
+            cur[m] = fetch(tq_begin - 12 + 36 * m);
         }
-        if (col == 252) v[3] = 0;
-        uint2 packed;
-        packed.x = (uint32_t)(v[0] & 0xFFFF) | ((uint32_t)v[1] << 16);
-        packed.y = (uint32_t)(v[2] & 0xFFFF) | ((uint32_t)v[3] << 16);
-        *reinterpret_cast<uint2 *>(s_s5 + row * kSPitch + col) = packed;
+        for (int tq = tq_begin; tq < tq_end; ++tq) {
+            const int tp = tq - 12;                     // t'
+#pragma unroll
+            for (int m = 0; m < 3; ++m) next[m] = fetch(tp + 36 * m + 1);
+            s16x2 S[2] = { { 0, 0 }, { 0, 0 } }, U[2] = { { 0, 0 }, { 0, 0 } }, V[2] = { { 0, 0 }, { 0, 0 } }, W[2] = { { 0, 0 }, { 0, 0 } };
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const int b = tp + 36 * m;
+                if (b < 0 || b >= kNumBlocks) continue;                       // wave-uniform
+                const uint32_t mid = cur[m];
+                const uint32_t up = b > 0 ? prev[m] : mid;                    // missing time neighbour: p - p = 0
+                const uint32_t dn = b + 1 < kNumBlocks ? next[m] : mid;
+                const uint32_t lnb = __shfl_up(mid, 1, 64), rnb = __shfl_down(mid, 1, 64);
+                const uint32_t left = lane > 0 ? lnb >> 24 : mid & 0xFFu;     // column 0 has no lower bin: p - p = 0
+                const uint32_t right = lane < 63 ? rnb & 0xFFu : 0u;          // column 255 is never addressed (f0 + tone <= 254)
+                const s16x2 c01 = bytes2(0, mid, 0x0c010c00u), c23 = bytes2(0, mid, 0x0c030c02u);
+                const s16x2 l01 = bytes2(left, mid, 0x0c000c04u), l23 = bytes2(0, mid, 0x0c020c01u);   // (left, m0), (m1, m2)
+                const s16x2 r23 = bytes2(right, mid, 0x0c040c03u);                                       // (m3, right); r01 = l23
+                const s16x2 u01 = bytes2(0, up, 0x0c010c00u), u23 = bytes2(0, up, 0x0c030c02u);
+                const s16x2 d01 = bytes2(0, dn, 0x0c010c00u), d23 = bytes2(0, dn, 0x0c030c02u);
+                const s16x2 dl0 = c01 - l01, dl1 = c23 - l23, dr0 = c01 - l23, dr1 = c23 - r23;
+                const s16x2 du0 = c01 - u01, du1 = c23 - u23, dd0 = c01 - d01, dd1 = c23 - d23;
+                S[0] += (dl0 + dr0) + (du0 + dd0);
+                S[1] += (dl1 + dr1) + (du1 + dd1);
+                U[0] += du0; U[1] += du1;
+                V[0] += dd0; V[1] += dd1;
+                W[0] += dl0; W[1] += dl1;
+            }
+            auto store = [&](int row, s16x2 a, s16x2 b2) {
+                uint2 v;
+                v.x = __builtin_bit_cast(uint32_t, a);
+                v.y = __builtin_bit_cast(uint32_t, b2);
+                *reinterpret_cast<uint2 *>(s_map + row * kMapPitch + 4 * lane) = v;
+            };
+            if (tp >= -11 && tp < 29) store(kOffA + tp + 11, S[0], S[1]);
+            if (tp >= -12 && tp < 24) store(kOff0 + tp + 12, S[0] - U[0], S[1] - U[1]);
+            if (tp >= -9 && tp < 27)  store(kOff3 + tp + 9, S[0] - W[0], S[1] - W[1]);
+            if (tp >= -6 && tp < 30)  store(kOff6 + tp + 6, S[0] - V[0], S[1] - V[1]);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) { prev[m] = cur[m]; cur[m] = next[m]; }
+        }
     }
-    __syncthreads();
-    // The map is built; column 255 of P is not read again (f0 + tone <= 254), so the byte left of every
-    // row's column 0 (= column 255 of the row above, or the last guard byte) can take a copy of column 0:
-    // p[f] - p[f-1] is then 0 at f = 0, which is the reference's "no lower bin" case.
-    if (tid < kNumBlocks) s_wf[tid * kPitch - 1] = s_wf[tid * kPitch];
     __syncthreads();
 
+    // ---- score all positions -----------------------------------------------------------------------
     const int sub = seg * kSyncWaves + wave;
     uint32_t *my_list = lists + ((size_t)frame * kSublistsPerFrame + sub) * kSublistCap;
     int count = 0;
@@ -162,21 +140,20 @@ void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lis
         const int t0 = t0i + kT0Min;
         const int navg = sync_navg(t0);
         // score /= navg (C int division, truncating toward zero) without an integer divide: with
-        // |score| <= 21*255 and navg <= 84 the quotient is either an integer or at least 1/84 away from
-        // one, while float(score)*fl(1/navg) is within 1e-3 of it, so adding 0.004 away from zero and
+        // |score| <= 21*4*255 and navg <= 84 the quotient is either an integer or at least 1/84 away from
+        // one, while float(score)*fl(1/navg) is within 2e-3 of it, so adding 0.004 away from zero and
         // truncating is exact.
         const float rnavg = navg > 0 ? 1.0f / (float)navg : 1.0f;
+        // row t0i of M0 / M3 / M6 is t' = t0 / t0 + 3 / t0 + 6; row t0i + k - 1 of MA is t' = t0 + k
+        const int16_t *ma = s_map + (kOffA + t0i) * kMapPitch;
+        const int16_t *m0 = s_map + (kOff0 + t0i) * kMapPitch, *m3 = s_map + (kOff3 + t0i) * kMapPitch, *m6 = s_map + (kOff6 + t0i) * kMapPitch;
 #pragma unroll 1
         for (int pass = 0; pass < 4; ++pass) {
             const int f0 = pass * 64 + lane;            // then freq_offset ascending
             const bool valid = f0 < kF0Count;
             const int fc = valid ? f0 : 0;
-            const uint8_t *pb = s_wf + t0 * kPitch + fc;
-            const int16_t *sb = s_s5 + t0 * kSPitch + fc;
-            int score;                                  // t0 is wave-uniform: one of three straight-line variants
-            if (t0 >= 1 && t0 <= 12) score = sync_sum<0>(pb, sb, t0);
-            else if (t0 <= 0) score = sync_sum<1>(pb, sb, t0);
-            else score = sync_sum<2>(pb, sb, t0);
+            int score = ((int)m0[fc + 3] + (int)ma[0 * kMapPitch + fc + 1] + (int)ma[1 * kMapPitch + fc + 4]) +
+                        ((int)m3[fc] + (int)ma[3 * kMapPitch + fc + 6] + (int)ma[4 * kMapPitch + fc + 5]) + (int)m6[fc + 2];
             {
                 const float fs_ = (float)score;
                 score = (int)(fs_ * rnavg + __builtin_copysignf(0.004f, fs_));
