@@ -3,138 +3,168 @@
 // K_MAX_MESSAGES = 50 slots keyed by message.hash % 50 with strcmp on the text (:1487-1507),
 // CQ-only spot fill via strtok semantics (:1509-1518), num_decoded++ for every unique message (:1520).
 //
-// The table walk is inherently sequential in candidate order (first duplicate wins, which fixes the
-// reported freq / snr), tiny, and byte-oriented.
+// The reference's table is a set: a message is new iff no EARLIER candidate of the frame carried the
+// same hash and strcmp-equal text, new messages are numbered in candidate order, and the table index
+// itself is never observable.  (With the table-full fence: the first 50 new messages are kept.)  That
+// is a data-parallel formulation: one wave per frame, lane = candidate, 64 candidates at a time.
+// Every lane checks its message against the messages kept so far and against the earlier lanes of its
+// chunk (16-bit hash first, text only on a hash match), a ballot + prefix popcount numbers the new
+// ones, and every new message parses its own text and writes its own spot record.  Texts, hashes and
+// candidates are staged in LDS, so the only global traffic is one coalesced fetch per candidate
+// record and the stores of the spot records.
 #include "ft8gpu_internal.h"
 
 namespace {
 
-// strcmp(a, b) == 0 on two message_t.text[25] fields in HBM: all 50 bytes are requested before the
-// first comparison, so the walk costs one memory round trip instead of one per character
-__device__ inline bool text_equal(const char *a, const char *b) {
-    char ta[25], tb[25];
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int kTextDw = 7;                    // message_t.text[25] in 7 aligned dwords (bytes 25..27 are 0)
+
+// strcmp(a, b) == 0 on two staged texts
+__device__ inline bool text_equal(const uint32_t *a, const uint32_t *b) {
+    uint32_t wa[kTextDw], wb[kTextDw];
 #pragma unroll
-    for (int i = 0; i < 25; ++i) { ta[i] = a[i]; tb[i] = b[i]; }
+    for (int i = 0; i < kTextDw; ++i) { wa[i] = a[i]; wb[i] = b[i]; }
     bool equal = true, open = true;                 // open: no terminator seen yet
 #pragma unroll
     for (int i = 0; i < 25; ++i) {
-        equal = equal && (!open || ta[i] == tb[i]);
-        open = open && ta[i] != 0;
+        const uint32_t ca = (wa[i >> 2] >> (8 * (i & 3))) & 0xFFu, cb = (wb[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+        equal = equal && (!open || ca == cb);
+        open = open && ca != 0;
     }
     return equal;
 }
 
-// strtok(text, " ") semantics: returns start index of the next token at or after *pos, or -1;
-// *len receives the token length, *pos is advanced past the token and one delimiter
+// strtok(text, " ") semantics on message_t.text with text[24] taken as the terminator (:1509 works on a
+// NUL-terminated char[25]): returns start index of the next token at or after *pos, or -1; *len
+// receives the token length, *pos is advanced past the token and one delimiter
 __device__ inline int next_token(const char *s, int *pos, int *len) {
     int p = *pos;
-    while (s[p] == ' ') ++p;
-    if (s[p] == 0) { *pos = p; return -1; }
+    while (p < 24 && s[p] == ' ') ++p;
+    if (p >= 24 || s[p] == 0) { *pos = p; return -1; }
     const int start = p;
-    while (s[p] != 0 && s[p] != ' ') ++p;
+    while (p < 24 && s[p] != 0 && s[p] != ' ') ++p;
     *len = p - start;
-    *pos = (s[p] == 0) ? p : p + 1;
+    *pos = (p >= 24 || s[p] == 0) ? p : p + 1;
     return start;
 }
 
-// snprintf(dst, cap, "%.<prec>s", tok) ; tok == NULL prints "(null)" (glibc)
+// snprintf(dst, cap, "%.<prec>s", tok) ; tok == NULL prints "(null)" (glibc).  tok points into LDS.
 __device__ inline void put_field(char *dst, int cap, int prec, const char *tok, int len) {
-    const char null_str[7] = { '(', 'n', 'u', 'l', 'l', ')', 0 };
-    if (tok == nullptr) { tok = null_str; len = 6; }
-    int n = len < prec ? len : prec;
-    if (n > cap - 1) n = cap - 1;
-    for (int i = 0; i < n; ++i) dst[i] = tok[i];
+    int n;
+    if (tok == nullptr) {
+        const uint64_t null_str = 0x00296C6C756E28ull;          // "(null)" little-endian
+        n = 6 < prec ? 6 : prec;
+        if (n > cap - 1) n = cap - 1;
+        for (int i = 0; i < n; ++i) dst[i] = (char)((null_str >> (8 * i)) & 0xFF);
+    } else {
+        n = len < prec ? len : prec;
+        if (n > cap - 1) n = cap - 1;
+        for (int i = 0; i < n; ++i) dst[i] = tok[i];
+    }
     dst[n] = 0;
 }
 
-// One wave per frame.  Lanes read the frame's candidate scores, `ok` flags and hashes in parallel
-// (coalesced) into LDS and reduce them to a bit mask of the candidates that reach the table code
-// (score gate :1467, ft8_decode() true :1476); lane 0 then walks only those, in candidate order,
-// through the reference's open-addressing table.  Texts are compared from HBM only on a hash match.
+// LDS per wave: staged texts [64][7 dw], candidates [64] and hashes [64] of the current chunk; texts
+// and hashes of the messages kept so far [50]
+struct SpotsWaveLds {
+    uint32_t ctext[64][kTextDw];
+    uint64_t ccand[64];
+    uint32_t ttext[kMaxMessages][kTextDw];
+    uint16_t chash[64];
+    uint16_t thash[kMaxMessages];
+};
+
 __global__ __launch_bounds__(256)
 void ft8_spots_kernel(const ft8gpu_candidate *__restrict__ cands, const int32_t *__restrict__ counts,
                       const ft8gpu_decode_status *__restrict__ status, int nframes, int max_candidates,
                       int min_score, struct decoder_results *__restrict__ decodes,
                       int32_t *__restrict__ n_results) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    __shared__ __attribute__((aligned(16))) SpotsWaveLds s_all[4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform by construction: keep it in an SGPR
     const int frame = blockIdx.x * 4 + wave;
     if (frame >= nframes) return;                                             // wave-uniform
-    const int words = (max_candidates + 63) / 64;
-    // per wave: live mask words | hash[max_candidates] | table[50]
-    const size_t per_wave = (size_t)words * 8 + (size_t)max_candidates * 2 + 2 * (kMaxMessages + 2);
-    unsigned char *base = s_dyn + (size_t)wave * ((per_wave + 15) & ~(size_t)15);
-    unsigned long long *live = reinterpret_cast<unsigned long long *>(base);
-    uint16_t *hashes = reinterpret_cast<uint16_t *>(base + (size_t)words * 8);
-    uint16_t *table = hashes + max_candidates;
+    SpotsWaveLds &L = s_all[wave];
 
     const ft8gpu_candidate *fc = cands + (size_t)frame * max_candidates;
     const ft8gpu_decode_status *fs = status + (size_t)frame * max_candidates;
     struct decoder_results *out = decodes + (size_t)frame * kMaxMessages;
     const int num_candidates = counts[frame];
+    const int words = (max_candidates + 63) / 64;
+    const unsigned long long below = (1ull << lane) - 1ull;
 
-    for (int w = 0; w < words; ++w) {
+    int num_decoded = 0;                                                      // wave-uniform
+    for (int w = 0; w < words; ++w) {                                         // :1465, candidate order
         const int idx = w * 64 + lane;
         bool ok = false;
+        uint64_t cand_bits = 0;
+        uint32_t my_hash = 0;
         if (idx < num_candidates) {
-            ok = fc[idx].score >= min_score && fs[idx].ok != 0;               // :1467, :1476-1485
-            hashes[idx] = fs[idx].crc_extracted;                              // message.hash
+            cand_bits = reinterpret_cast<const uint64_t *>(fc)[idx];
+            const uint32_t st2 = reinterpret_cast<const uint32_t *>(fs + idx)[2];                 // unpack_status | ok << 8 | a91[0..1]
+            ok = (int16_t)(cand_bits & 0xFFFFu) >= min_score && ((st2 >> 8) & 0xFFu) != 0;        // :1467, :1476-1485
         }
-        const unsigned long long m = __ballot(ok);
-        if (lane == 0) live[w] = m;
-    }
-    if (lane < kMaxMessages) table[lane] = 0;                                 // :1458-1460
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane != 0) return;
-
-    int num_decoded = 0;
-    for (int w = 0; w < words; ++w) {
-        unsigned long long m = live[w];
-        while (m) {                                                           // :1465, candidate order
-            const int idx = w * 64 + __builtin_ctzll(m);
-            m &= m - 1;
-            const uint16_t hash = hashes[idx];
-            int idx_hash = hash % kMaxMessages;                               // :1487
-            bool found_empty_slot = false, found_duplicate = false;
-            int probes = 0;
-            do {
-                const int t = table[idx_hash];
-                if (t == 0) {
-                    found_empty_slot = true;
-                } else if (hashes[t - 1] == hash && text_equal(fs[t - 1].text, fs[idx].text)) {
-                    found_duplicate = true;
-                } else {
-                    idx_hash = (idx_hash + 1) % kMaxMessages;
-                    if (++probes >= kMaxMessages) break;  // table full: drop (reference never terminates here)
-                }
-            } while (!found_empty_slot && !found_duplicate);
-
-            if (found_empty_slot) {                                           // :1505
-                table[idx_hash] = (uint16_t)(idx + 1);
-                char text[25];
-                for (int i = 0; i < 25; ++i) text[i] = fs[idx].text[i];
-                text[24] = 0;
-                int pos = 0, len = 0;
-                const int t0 = next_token(text, &pos, &len);                  // :1509
-                if (t0 >= 0 && len >= 2 && text[t0] == 'C' && text[t0 + 1] == 'Q') {   // :1510 strncmp(.., "CQ", 2)
-                    const ft8gpu_candidate cand = fc[idx];
-                    const float freq_hz = (cand.freq_offset + (float)cand.freq_sub / 2) * 6.25f;   // :1470
-                    int l1 = 0, l2 = 0;
-                    const int t1 = next_token(text, &pos, &l1);
-                    put_field(out[num_decoded].call, 13, 12, t1 >= 0 ? text + t1 : nullptr, l1);   // :1512
-                    const int t2 = next_token(text, &pos, &l2);
-                    put_field(out[num_decoded].loc, 7, 6, t2 >= 0 ? text + t2 : nullptr, l2);      // :1514
-                    out[num_decoded].freq = (int32_t)freq_hz;                 // :1516
-                    out[num_decoded].snr = (int32_t)cand.score;               // :1517
-                }
-                num_decoded++;                                                // :1520
+        const unsigned long long live = __ballot(ok);
+        if (live == 0ull) continue;                                           // wave-uniform
+        if (ok) {
+            const uint32_t *rec = reinterpret_cast<const uint32_t *>(fs + idx);                   // 48-byte record, 12 dwords
+            my_hash = rec[1] & 0xFFFFu;                                                           // crc_extracted = message.hash
+            L.chash[lane] = (uint16_t)my_hash;
+            L.ccand[lane] = cand_bits;
+            uint32_t r[8];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) r[k] = rec[5 + k];                    // bytes 20..47; text starts at byte 22
+            r[7] = 0;
+#pragma unroll
+            for (int k = 0; k < kTextDw; ++k) {
+                uint32_t v = (r[k] >> 16) | (r[k + 1] << 16);
+                if (k == kTextDw - 1) v &= 0xFFu;                             // text[24] only (byte 47 is the record's pad)
+                L.ctext[lane][k] = v;
             }
         }
+        wave_lds_sync();
+
+        // :1487-1503 -- is the message already known?  Against the kept messages, then against the
+        // earlier live lanes of this chunk (both loops have wave-uniform trip counts).
+        bool dup = false;
+        for (int t = 0; t < num_decoded; ++t)
+            if (ok && L.thash[t] == my_hash && text_equal(L.ttext[t], L.ctext[lane])) dup = true;
+        for (unsigned long long m = live; m != 0ull; m &= m - 1) {
+            const int j = __builtin_ctzll(m);                                 // wave-uniform
+            if (ok && j < lane && L.chash[j] == my_hash && text_equal(L.ctext[j], L.ctext[lane])) dup = true;
+        }
+        const unsigned long long fresh = __ballot(ok && !dup);
+        const int rank = num_decoded + __popcll(fresh & below);               // position among the frame's unique messages
+        const bool keep = ok && !dup && rank < kMaxMessages;                  // table full: drop (the reference never terminates there)
+        if (keep) {                                                           // :1505-1520
+#pragma unroll
+            for (int k = 0; k < kTextDw; ++k) L.ttext[rank][k] = L.ctext[lane][k];
+            L.thash[rank] = (uint16_t)my_hash;
+            const char *text = reinterpret_cast<const char *>(L.ctext[lane]);
+            int pos = 0, len = 0;
+            const int t0 = next_token(text, &pos, &len);                      // :1509
+            if (t0 >= 0 && len >= 2 && text[t0] == 'C' && text[t0 + 1] == 'Q') {   // :1510 strncmp(.., "CQ", 2)
+                const int score = (int16_t)(cand_bits & 0xFFFFu), freq_offset = (int16_t)((cand_bits >> 32) & 0xFFFFu);
+                const int freq_sub = (int)((cand_bits >> 56) & 0xFFu);
+                const float freq_hz = (freq_offset + (float)freq_sub / 2) * 6.25f;                  // :1470
+                int l1 = 0, l2 = 0;
+                const int t1 = next_token(text, &pos, &l1);
+                put_field(out[rank].call, 13, 12, t1 >= 0 ? text + t1 : nullptr, l1);              // :1512
+                const int t2 = next_token(text, &pos, &l2);
+                put_field(out[rank].loc, 7, 6, t2 >= 0 ? text + t2 : nullptr, l2);                 // :1514
+                out[rank].freq = (int32_t)freq_hz;                            // :1516
+                out[rank].snr = (int32_t)score;                               // :1517
+            }
+        }
+        num_decoded += __popcll(__ballot(keep));                              // :1520
+        wave_lds_sync();                                                      // staging rows are rewritten by the next 64
     }
-    n_results[frame] = num_decoded;                                           // :1523
+    if (lane == 0) n_results[frame] = num_decoded;                            // :1523
 }
 
 }  // namespace
@@ -143,9 +173,7 @@ hipError_t launch_spots(const ft8gpu_candidate *cands, const int32_t *counts,
                         const ft8gpu_decode_status *status, int nframes, int max_candidates,
                         int min_score, struct decoder_results *decodes, int32_t *n_results, hipStream_t s) {
     if (nframes < 1) return hipSuccess;
-    const int words = (max_candidates + 63) / 64;
-    const size_t per_wave = ((size_t)words * 8 + (size_t)max_candidates * 2 + 2 * (kMaxMessages + 2) + 15) & ~(size_t)15;
-    hipLaunchKernelGGL(ft8_spots_kernel, dim3((nframes + 3) / 4), dim3(256), 4 * per_wave, s,
+    hipLaunchKernelGGL(ft8_spots_kernel, dim3((nframes + 3) / 4), dim3(256), 0, s,
                        cands, counts, status, nframes, max_candidates, min_score, decodes, n_results);
     return hipGetLastError();
 }
