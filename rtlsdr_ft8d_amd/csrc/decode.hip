@@ -119,6 +119,36 @@ __device__ __forceinline__ f2 atanh_pair(f2 x) {
     return FAST ? div_pair_fast(a, b) : div_pair_ieee(a, b);
 }
 
+// The ninth edge of a lane has no partner: the same functions on one float (a packed instruction
+// costs about 1.7 scalar ones on gfx950, so half-empty pairs are not free)
+__device__ __forceinline__ float div_one_fast(float a, float b) {
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float e0 = __builtin_fmaf(-b, r0, 1.0f);
+    const float r1 = __builtin_fmaf(e0, r0, r0);
+    const float q0 = a * r1;
+    const float e1 = __builtin_fmaf(-b, q0, a);
+    const float q1 = __builtin_fmaf(e1, r1, q0);
+    const float e2 = __builtin_fmaf(-b, q1, a);
+    return __builtin_fmaf(e2, r1, q1);
+}
+
+template <bool FAST>
+__device__ __forceinline__ float tanh_one(float x) {
+    const float x2 = x * x;
+    const float a = x * (945.0f + x2 * (105.0f + x2));
+    const float b = 945.0f + x2 * (420.0f + x2 * 15.0f);
+    const float r = FAST ? div_one_fast(a, b) : __fdiv_rn(a, b);
+    return (__builtin_fabsf(x) > 4.97f) ? __builtin_copysignf(1.0f, x) : r;
+}
+
+template <bool FAST>
+__device__ __forceinline__ float atanh_one(float x) {
+    const float x2 = x * x;
+    const float a = x * (945.0f + x2 * (-735.0f + x2 * 64.0f));
+    const float b = (945.0f + x2 * (-1050.0f + x2 * 225.0f));
+    return FAST ? div_one_fast(a, b) : __fdiv_rn(a, b);
+}
+
 // Guard key of a value: (bits << 1) - 1 as unsigned.  Zero maps to 0xFFFFFFFF, every other value to
 // twice its magnitude bits minus one, so "minimum key over a set >= key(T)" says: each member is
 // zero or at least T in magnitude.
@@ -292,7 +322,7 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
     // chosen so that the sums below are packed adds on whole register pairs without any shuffling:
     //   u_r = cwh_r + ah[r][0]                    (u_0, u_1) = cwh01 + B
     //   X[r] = (x[r][1], x[r][2]) = u_r + A[r]    Tnm of edge 1 omits ah[r][1], of edge 2 omits ah[r][2]
-    //   x[r][0] = (cwh_r + ah[r][1]) + ah[r][2]   -> Y = (x[0][0], x[1][0]),  Z = (x[2][0], 0)
+    //   x[r][0] = (cwh_r + ah[r][1]) + ah[r][2]   -> Y = (x[0][0], x[1][0]),  z = x[2][0] (scalar)
     //   hard decision: (u_r + ah[r][1]) + ah[r][2] = X[r].y + A[r].x
     // Which values share a register pair is free (every value is computed by the same operations in
     // the same order whatever its neighbour is); the LDS slot of every edge is a per-lane constant.
@@ -312,7 +342,8 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
     for (; iter < max_iters; ++iter) {
         // hard decision (tov = 0 in iteration 0) and Tnm / x for the lane's nine edges
         // (lanes without a third variable compute on spare-row content and write to the spare row)
-        f2 X[3], Y, Z;
+        f2 X[3], Y;
+        float z;
         if (fast_ok) {
             const f2 u01 = cwh01 + B;
             const float u2 = cwh[2] + c2;
@@ -322,7 +353,7 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
             // (scalar adds: written opaquely, otherwise the vectoriser pairs them up behind four v_mov)
             Y.x = add_f32(add_f32(cwh[0], A[0].y), A[0].x);
             Y.y = add_f32(add_f32(cwh[1], A[1].y), A[1].x);
-            Z.x = add_f32(add_f32(cwh[2], A[2].y), A[2].x);
+            z = add_f32(add_f32(cwh[2], A[2].y), A[2].x);
             B0 = __ballot((X[0].y + A[0].x) < 0.0f);               // lanes 0..63 all own variables 0..127
             B1 = __ballot((X[1].y + A[1].x) < 0.0f);
             B2 = __ballot((X[2].y + A[2].x) < 0.0f) & has2_mask;
@@ -341,12 +372,11 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
             }
             Y.x = x0[0];
             Y.y = x0[1];
-            Z.x = x0[2];
+            z = x0[2];
             B0 = __ballot(bit[0]);
             B1 = __ballot(bit[1]);
             B2 = __ballot(bit[2]);
         }
-        Z.y = 0.0f;
         if ((B0 | B1 | B2) == 0ull) break;              // all-zero word is prohibited
 
         // ldpc_check
@@ -378,17 +408,18 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
 
         // ---- bits -> checks: toc[m][n_idx] = fast_tanh(-Tnm / 2) -------------------------------
         {
-            f2 t[5];
+            f2 t[4];
+            float tz;
             if (fast_ok) {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) t[r] = tanh_pair<true>(X[r]);
                 t[3] = tanh_pair<true>(Y);
-                t[4] = tanh_pair<true>(Z);
+                tz = tanh_one<true>(z);
             } else {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) t[r] = tanh_pair<false>(X[r]);
                 t[3] = tanh_pair<false>(Y);
-                t[4] = tanh_pair<false>(Z);
+                tz = tanh_one<false>(z);
             }
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
@@ -397,7 +428,7 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
             }
             toc[slot[0]] = t[3].x;
             toc[slot[3]] = t[3].y;
-            toc[slot[6]] = t[4].x;
+            toc[slot[6]] = tz;
         }
         wave_lds_sync();
 
@@ -423,34 +454,32 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
 
         // ---- checks -> bits: tov[n][m_idx] = -2 * fast_atanh(product of the other toc of the row); the
         // state kept is fast_atanh(...) itself, i.e. tov = -2 * state exactly (half domain) -------------
-        f2 PA[3], PB, PC;
+        f2 PA[3], PB;
 #pragma unroll
         for (int r = 0; r < 2; ++r) PA[r] = f2{ toc[slot[3 * r + 2]], toc[slot[3 * r + 1]] };
         PB = f2{ toc[slot[0]], toc[slot[3]] };
         PA[2] = f2{ toc[slot[8]], toc[slot[7]] };
-        PC = f2{ toc[slot[6]], 0.0f };
+        const float pc = toc[slot[6]];
         // Lanes without a third variable run these three edges on whatever the spare row holds; nothing
         // they compute leaves the spare row or their own registers (their decision bit is masked), so the
         // guard ignores them.
-        uint32_t g2 = min(guard_key(PC.x), min(guard_key(PA[2].x), guard_key(PA[2].y)));
+        uint32_t g2 = min(guard_key(pc), min(guard_key(PA[2].x), guard_key(PA[2].y)));
         g2 = has[2] ? g2 : 0xFFFFFFFFu;
         uint32_t gmin = min(g2, min(guard_key(PB.x), guard_key(PB.y)));
 #pragma unroll
         for (int r = 0; r < 2; ++r) gmin = min(gmin, min(guard_key(PA[r].x), guard_key(PA[r].y)));
         fast_ok = __all(gmin >= kGuardMin) && !force_ieee_div;       // wave-uniform; also governs the next tanh phase
-        f2 C;
         if (fast_ok) {
 #pragma unroll
             for (int r = 0; r < 3; ++r) A[r] = atanh_pair<true>(PA[r]);
             B = atanh_pair<true>(PB);
-            C = atanh_pair<true>(PC);
+            c2 = atanh_one<true>(pc);
         } else {
 #pragma unroll
             for (int r = 0; r < 3; ++r) A[r] = atanh_pair<false>(PA[r]);
             B = atanh_pair<false>(PB);
-            C = atanh_pair<false>(PC);
+            c2 = atanh_one<false>(pc);
         }
-        c2 = C.x;
         // (the next iteration's toc stores hit only this lane's own slots; LDS is in order per wave)
     }
 
