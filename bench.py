@@ -8,7 +8,8 @@ A step = one pass of the whole decode path (waterfall FFT -> Costas sync -> LLR 
 unpack -> dedup/spots) over the rank's batch of synthetic 15 s frames, resident in HBM before the
 timed region starts.  Frames are independent, so N GPUs each take a contiguous shard of the global
 batch (weak scaling: frames per GPU fixed); the only collective is one RCCL all-gather of the
-fixed-size spot records per step.  Prints ONE JSON line on rank 0.
+fixed-size spot records per step, double-buffered so that it runs under the next step's kernels.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -77,15 +78,21 @@ def main():
     sig, _ = workload.frame_signals(lo, B, args.nsig, pool_tones, snr_range=tuple(args.snr))
     iq = torch.empty((B, 2, ft8.NSAMPLES), dtype=torch.float32, device=dev)
     dec.synth_frames(sig, B, args.nsig, 1.0, workload.SEED_BASE + lo, iq)
-    spots = torch.zeros((B, ft8.MAX_MESSAGES * 28), dtype=torch.uint8, device=dev)
-    nres = torch.zeros((B,), dtype=torch.int32, device=dev)
+    # spot records: two buffers per rank; the exchange of step k (one asynchronous RCCL all-gather of
+    # records + counts) runs under the kernels of step k + 1 and is drained inside the timed region
+    exch = workload.SpotExchange(B, world, dev, collective=use_dist)
+    spots, nres = exch.buffers(0)
+    state = {"k": 0}
 
     def step():
-        dec.decode_batch_dev(iq, B, spots, nres)
-        if use_dist:         # the spot list of the whole job on every rank: one RCCL all-gather each
-            workload.gather_spots(spots, nres, world)
+        k = state["k"]
+        s_buf, n_buf = exch.buffers(k)                  # waits for the exchange that last used this buffer
+        dec.decode_batch_dev(iq, B, s_buf, n_buf)
+        exch.launch(k)                                  # the whole job's spot list on every rank
+        state["k"] = k + 1
 
     def fence():
+        exch.wait_all()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -102,6 +109,7 @@ def main():
     stage_avg = dec.timings()        # mean over the timed steps (ring of the last 32)
     timed_runs = stage_avg.pop("runs")
     dec.enable_timing(False)
+    spots, nres = exch.buffers(state["k"] - 1) if state["k"] > 0 else (spots, nres)    # the last step's local records
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if use_dist:
@@ -158,6 +166,11 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         sys.stderr.flush()
+        try:                                        # RCCL writes its banner through C stdio, which is fully buffered
+            import ctypes                           # on a pipe: push it out before the JSON line, not at exit
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(json.dumps(out), flush=True)          # the one JSON line, after any library banners
 
 

@@ -72,3 +72,64 @@ def gather_spots(spots, n_results, world_size):
     dist.all_gather_into_tensor(all_spots, spots)
     dist.all_gather_into_tensor(all_counts, n_results)
     return all_spots, all_counts
+
+
+class SpotExchange:
+    """Double-buffered spot records of one rank and their exchange as ONE asynchronous all-gather.
+
+    A rank's step k writes its [frames][50 x 28 B] records and [frames] int32 counts into buffer k % 2
+    (one flat allocation: records, then counts), `launch(k)` starts the all-gather of that buffer on the
+    process group's own stream (it waits for the kernels enqueued so far on the current stream), and the
+    next step's kernels are enqueued behind it without waiting: the collective (5.7 MB per rank and
+    step at 4096 frames) runs under the next batch's decode.  A buffer is waited for just before it is
+    reused, and `wait_all()` drains everything (bench.py calls it inside the timed region).
+    Works on RCCL (device tensors) and on gloo (CPU tensors, tests/test_dist_gloo.py)."""
+
+    RECORD_BYTES = 1400
+
+    def __init__(self, frames, world_size, device, collective=None):
+        import torch
+        self.frames, self.world = frames, world_size
+        self.collective = (world_size > 1) if collective is None else collective     # True forces it for one rank too
+        seg = frames * (self.RECORD_BYTES + 4)
+        self._local = [torch.zeros(seg, dtype=torch.uint8, device=device) for _ in range(2)]
+        self._all = [torch.zeros(seg * world_size, dtype=torch.uint8, device=device) for _ in range(2)] if self.collective else None
+        self._work = [None, None]
+
+    def buffers(self, k):
+        """(spots [frames, 1400] uint8, counts [frames] int32) of step k; waits for the exchange that last used them"""
+        i = k & 1
+        if self._work[i] is not None:
+            self._work[i].wait()
+            self._work[i] = None
+        flat = self._local[i]
+        n = self.frames * self.RECORD_BYTES
+        return flat[:n].view(self.frames, self.RECORD_BYTES), flat[n:].view(dtype=__import__("torch").int32)
+
+    def launch(self, k):
+        import torch.distributed as dist
+        if self.collective:
+            i = k & 1
+            self._work[i] = dist.all_gather_into_tensor(self._all[i], self._local[i], async_op=True)
+
+    def wait_all(self):
+        for i in (0, 1):
+            if self._work[i] is not None:
+                self._work[i].wait()
+                self._work[i] = None
+
+    def gathered(self, k):
+        """(all_spots [world*frames, 1400], all_counts [world*frames]) of step k in global frame order (copies)"""
+        import torch
+        i = k & 1
+        if self._work[i] is not None:
+            self._work[i].wait()
+            self._work[i] = None
+        if not self.collective:
+            s, c = self._local[i][:self.frames * self.RECORD_BYTES], self._local[i][self.frames * self.RECORD_BYTES:]
+            return s.view(self.frames, self.RECORD_BYTES).clone(), c.view(dtype=torch.int32).clone()
+        seg = self._all[i].view(self.world, -1)
+        n = self.frames * self.RECORD_BYTES
+        spots = seg[:, :n].reshape(self.world * self.frames, self.RECORD_BYTES)
+        counts = seg[:, n:].contiguous().view(dtype=torch.int32).reshape(-1)
+        return spots, counts

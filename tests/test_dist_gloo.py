@@ -41,6 +41,18 @@ def _worker(rank, world, port, total, q):
     all_spots, all_counts = workload.gather_spots(spots, counts, world)
     ref_spots, ref_counts = _fake_spots(0, total)
     ok = bool(torch.equal(all_spots, ref_spots) and torch.equal(all_counts, ref_counts))
+    # the double-buffered, single-collective, asynchronous form bench.py uses: three steps, each step's
+    # records shifted by the step number so that a stale or swapped buffer would show
+    ex = workload.SpotExchange(hi - lo, world, "cpu")
+    for k in range(3):
+        s_buf, c_buf = ex.buffers(k)
+        s_buf.copy_((spots.to(torch.int32) + k).to(torch.uint8))
+        c_buf.copy_(counts + k)
+        ex.launch(k)
+    for k in (1, 2):                       # the last two steps are still held (two buffers)
+        g_s, g_c = ex.gathered(k)
+        ok = ok and bool(torch.equal(g_s, (ref_spots.to(torch.int32) + k).to(torch.uint8)) and torch.equal(g_c, ref_counts + k))
+    ex.wait_all()
     # max-over-ranks timing reduction used by bench.py
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
