@@ -90,7 +90,10 @@ void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lis
             const int tp = tq - 12;                     // t'
 #pragma unroll
             for (int m = 0; m < 3; ++m) next[m] = fetch(tp + 36 * m + 1);
-            s16x2 S[2] = { { 0, 0 }, { 0, 0 } }, U[2] = { { 0, 0 }, { 0, 0 } }, V[2] = { { 0, 0 }, { 0, 0 } }, W[2] = { { 0, 0 }, { 0, 0 } };
+            // Sums of the centre bytes and of each neighbour over the valid m; the differences are formed
+            // once per cell afterwards (sum(c - x) = sum(c) - sum(x)); |sums| <= 3 * 255.
+            s16x2 C[2] = { { 0, 0 }, { 0, 0 } }, L[2] = { { 0, 0 }, { 0, 0 } }, R[2] = { { 0, 0 }, { 0, 0 } };
+            s16x2 Up[2] = { { 0, 0 }, { 0, 0 } }, Dn[2] = { { 0, 0 }, { 0, 0 } };
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 const int b = tp + 36 * m;
@@ -101,18 +104,20 @@ void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lis
                 const uint32_t lnb = __shfl_up(mid, 1, 64), rnb = __shfl_down(mid, 1, 64);
                 const uint32_t left = lane > 0 ? lnb >> 24 : mid & 0xFFu;     // column 0 has no lower bin: p - p = 0
                 const uint32_t right = lane < 63 ? rnb & 0xFFu : 0u;          // column 255 is never addressed (f0 + tone <= 254)
-                const s16x2 c01 = bytes2(0, mid, 0x0c010c00u), c23 = bytes2(0, mid, 0x0c030c02u);
-                const s16x2 l01 = bytes2(left, mid, 0x0c000c04u), l23 = bytes2(0, mid, 0x0c020c01u);   // (left, m0), (m1, m2)
-                const s16x2 r23 = bytes2(right, mid, 0x0c040c03u);                                       // (m3, right); r01 = l23
-                const s16x2 u01 = bytes2(0, up, 0x0c010c00u), u23 = bytes2(0, up, 0x0c030c02u);
-                const s16x2 d01 = bytes2(0, dn, 0x0c010c00u), d23 = bytes2(0, dn, 0x0c030c02u);
-                const s16x2 dl0 = c01 - l01, dl1 = c23 - l23, dr0 = c01 - l23, dr1 = c23 - r23;
-                const s16x2 du0 = c01 - u01, du1 = c23 - u23, dd0 = c01 - d01, dd1 = c23 - d23;
-                S[0] += (dl0 + dr0) + (du0 + dd0);
-                S[1] += (dl1 + dr1) + (du1 + dd1);
-                U[0] += du0; U[1] += du1;
-                V[0] += dd0; V[1] += dd1;
-                W[0] += dl0; W[1] += dl1;
+                const s16x2 m12 = bytes2(0, mid, 0x0c020c01u);                // (m1, m2): right of (m0, m1), left of (m2, m3)
+                C[0] += bytes2(0, mid, 0x0c010c00u);   C[1] += bytes2(0, mid, 0x0c030c02u);
+                L[0] += bytes2(left, mid, 0x0c000c04u); L[1] += m12;          // (left, m0), (m1, m2)
+                R[0] += m12;                            R[1] += bytes2(right, mid, 0x0c040c03u);   // (m1, m2), (m3, right)
+                Up[0] += bytes2(0, up, 0x0c010c00u);   Up[1] += bytes2(0, up, 0x0c030c02u);
+                Dn[0] += bytes2(0, dn, 0x0c010c00u);   Dn[1] += bytes2(0, dn, 0x0c030c02u);
+            }
+            s16x2 S[2], U[2], V[2], W[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                W[h] = C[h] - L[h];                                           // sum of dl
+                U[h] = C[h] - Up[h];                                          // sum of du
+                V[h] = C[h] - Dn[h];                                          // sum of dd
+                S[h] = (W[h] + (C[h] - R[h])) + (U[h] + V[h]);                // sum of dl + dr + du + dd
             }
             auto store = [&](int row, s16x2 a, s16x2 b2) {
                 uint2 v;
