@@ -185,6 +185,11 @@ void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lis
 // by lane 0 through the reference's insertion / eviction / heapify rules.  The final heap sort is
 // replayed the same way, so ties come out in exactly the reference's order.
 __device__ __forceinline__ int sc(uint64_t e) { return (int)(int16_t)(e & 0xFFFFu); }
+__device__ __forceinline__ void wave_lds_sync_heap() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 __device__ __forceinline__ void heapify_down(uint64_t *heap, int heap_size) {
     int current = 0;
@@ -215,16 +220,153 @@ __device__ __forceinline__ void heapify_up(uint64_t *heap, int heap_size) {
     heap[current] = cur;
 }
 
+// ---- register-resident form of the same replay (max_candidates <= 128) -----------------------------
+// The replay is a chain of dependent compare-and-move steps; with the heap in LDS every step pays an LDS
+// round trip from a single active lane.  Here the heap array lives in two VGPRs across the wave as 32-bit
+// keys  score << 16 | entry id  -- node j in lane j >> 1 of kE (j even) or kO (j odd), so the root is
+// kE[0] and the children of node c are kO[c] and kE[c + 1] -- every index is wave-uniform, and the whole
+// control flow runs on the scalar unit with v_readlane / v_writelane, free of data-dependent branches
+// except the loop exits; LDS only keeps the 64-bit entries, addressed by id.  Same comparisons and moves in
+// the same order as heapify_up / heapify_down above.
+}  // namespace
+// v_writelane_b32 (this hipcc declares no builtin for it; the LLVM intrinsic is bound by name)
+extern "C" __device__ int ft8_writelane_i32(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+namespace {
+
+struct HeapRegs {
+    uint32_t kE, kO;                                             // nodes 2*lane and 2*lane + 1
+    __device__ __forceinline__ uint32_t get(int j) const {
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)kE, j >> 1), o = (uint32_t)__builtin_amdgcn_readlane((int)kO, j >> 1);
+        return (j & 1) ? o : e;
+    }
+    __device__ __forceinline__ void set(int j, uint32_t v) {     // rewrites both registers' lane, one of them with its own value
+        const int l = j >> 1;
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)kE, l), o = (uint32_t)__builtin_amdgcn_readlane((int)kO, l);
+        kE = (uint32_t)ft8_writelane_i32((int)((j & 1) ? e : v), l, (int)kE);
+        kO = (uint32_t)ft8_writelane_i32((int)((j & 1) ? v : o), l, (int)kO);
+    }
+    __device__ __forceinline__ uint32_t root() const { return (uint32_t)__builtin_amdgcn_readlane((int)kE, 0); }
+};
+__device__ __forceinline__ int hk_sc(uint32_t key) { return (int)key >> 16; }
+
+__device__ __forceinline__ void hk_sift_down(HeapRegs &h, int heap_size, uint32_t cur) {   // cur enters at the root
+    int current = 0;
+    while (true) {
+        const int left = 2 * current + 1, right = left + 1;
+        if (left >= heap_size) break;                                        // no child: (largest == current)
+        const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)h.kO, current);       // node 2c + 1
+        const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)h.kE, current + 1);   // node 2c + 2 (ignored if outside)
+        const bool take_l = hk_sc(l) < hk_sc(cur);
+        const uint32_t lv = take_l ? l : cur;
+        const bool take_r = right < heap_size && hk_sc(r) < hk_sc(lv);
+        if (!take_l && !take_r) break;
+        h.set(current, take_r ? r : l);
+        current = take_r ? right : left;
+    }
+    h.set(current, cur);
+}
+
+__device__ __forceinline__ void hk_sift_up(HeapRegs &h, int heap_size, uint32_t cur) {     // cur enters at the last node
+    int current = heap_size - 1;
+    while (current > 0) {
+        const int parent = (current - 1) / 2;
+        const uint32_t pv = h.get(parent);
+        if (hk_sc(cur) >= hk_sc(pv)) break;
+        h.set(current, pv);
+        current = parent;
+    }
+    h.set(current, cur);
+}
+
+__device__ __forceinline__ void heap_select_regs(const uint32_t *__restrict__ frame_lists, const int32_t *__restrict__ frame_counts,
+                                                 uint64_t *ent, uint64_t *out, int32_t *count_out, int max_candidates, int lane) {
+    HeapRegs h = { 0u, 0u };
+    int heap_size = 0;                                           // wave-uniform, like every index below
+    // Memory latency must stay out of the dependent chain: the 32 sub-list lengths arrive with one load, and
+    // the entries of the next 64-entry chunk are requested before the current chunk is replayed.
+    static_assert(kSublistsPerFrame <= 64, "one lane per sub-list length");
+    const int my_n = lane < kSublistsPerFrame ? frame_counts[lane] : 0;
+    auto count_of = [&](int sub) { return __builtin_amdgcn_readlane(my_n, sub); };
+    auto advance = [&](int &sub, int &base) {                    // next non-empty chunk in (sub-list, offset) order
+        base += 64;
+        while (sub < kSublistsPerFrame && (sub < 0 || base >= count_of(sub))) { ++sub; base = 0; }
+    };
+    auto fetch = [&](int sub, int base) -> uint32_t {
+        if (sub >= kSublistsPerFrame) return 0u;
+        const int e = base + lane;
+        return e < count_of(sub) ? frame_lists[(size_t)sub * kSublistCap + e] : 0u;
+    };
+    int sub = -1, base = 0;
+    advance(sub, base);
+    uint32_t v_cur = fetch(sub, base);
+    while (sub < kSublistsPerFrame) {                            // (time_sub, freq_sub, time_offset) order
+        int nsub = sub, nbase = base;
+        advance(nsub, nbase);
+        const uint32_t v_next = fetch(nsub, nbase);              // in flight while this chunk is replayed
+        const int n = count_of(sub);
+        const uint32_t seg = (uint32_t)(sub / kSyncWaves);
+        uint64_t c = 0;
+        bool live = base + lane < n;
+        if (live) {
+            const uint32_t v = v_cur;
+            const uint32_t score = v >> 16;
+            const uint32_t t0 = (uint32_t)(int)((int)((v >> 8) & 0xFF) + kT0Min) & 0xFFFFu;
+            c = (uint64_t)score | ((uint64_t)t0 << 16) | ((uint64_t)(v & 0xFF) << 32) |
+                ((uint64_t)(seg >> 1) << 48) | ((uint64_t)(seg & 1) << 56);
+            // prefilter against the current minimum (it can only grow while this chunk is replayed)
+            if (heap_size == max_candidates && !(sc(c) > hk_sc(h.root()))) live = false;
+        }
+        const uint32_t my_score16 = (uint32_t)(c & 0xFFFFu);
+        for (unsigned long long mask = __ballot(live); mask != 0ull; mask &= mask - 1) {
+            const int j = __builtin_ctzll(mask);                                  // list order
+            const uint32_t s16 = (uint32_t)__builtin_amdgcn_readlane((int)my_score16, j);
+            const int score = (int)(int16_t)s16;
+            int id = heap_size;                                                   // ids 0..cap-1 are handed out in order while filling
+            if (heap_size == max_candidates && score > hk_sc(h.root())) {
+                id = (int)(h.root() & 0xFFFFu);                                   // the evicted root's entry slot is reused
+                const uint32_t last = h.get(heap_size - 1);
+                --heap_size;
+                hk_sift_down(h, heap_size, last);
+            }
+            if (heap_size < max_candidates) {
+                if (lane == j) ent[id] = c;
+                ++heap_size;
+                hk_sift_up(h, heap_size, (s16 << 16) | (uint32_t)id);
+            }
+        }
+        sub = nsub;
+        base = nbase;
+        v_cur = v_next;
+    }
+    // heap sort (descending), replayed on the keys
+    for (int len_unsorted = heap_size; len_unsorted > 1;) {
+        const uint32_t tmp = h.get(len_unsorted - 1);
+        h.set(len_unsorted - 1, h.root());
+        len_unsorted--;
+        hk_sift_down(h, len_unsorted, tmp);
+    }
+    if (lane == 0) *count_out = heap_size;
+    wave_lds_sync_heap();
+    // node j sits in lane j >> 1: lane l stores nodes 2l and 2l + 1 (8-byte stores, pairs adjacent)
+    if (2 * lane < max_candidates) out[2 * lane] = 2 * lane < heap_size ? ent[h.kE & 0xFFFFu] : 0ull;            // deterministic tail
+    if (2 * lane + 1 < max_candidates) out[2 * lane + 1] = 2 * lane + 1 < heap_size ? ent[h.kO & 0xFFFFu] : 0ull;
+}
+
 __global__ __launch_bounds__(256)
 void ft8_heap_kernel(const uint32_t *__restrict__ lists, const int32_t *__restrict__ list_counts,
                      ft8gpu_candidate *__restrict__ cands, int32_t *__restrict__ counts,
-                     int nframes, int max_candidates) {
+                     int nframes, int max_candidates, int register_form) {
     extern __shared__ __attribute__((aligned(16))) uint64_t s_heap_all[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform by construction: keep it in an SGPR
     const int frame = blockIdx.x * 4 + wave;
     if (frame >= nframes) return;                                // wave-uniform
     uint64_t *heap = s_heap_all + (size_t)wave * (max_candidates + 64);
+    if (register_form) {                                         // wave-uniform
+        heap_select_regs(lists + (size_t)frame * kSublistsPerFrame * kSublistCap, list_counts + (size_t)frame * kSublistsPerFrame,
+                         heap, reinterpret_cast<uint64_t *>(cands) + (size_t)frame * max_candidates, counts + frame, max_candidates, lane);
+        return;
+    }
     uint64_t *stage = heap + max_candidates;                     // 64 staged survivors
     int heap_size = 0;
 
@@ -305,7 +447,12 @@ hipError_t launch_heap(const uint32_t *lists, const int32_t *list_counts, ft8gpu
                        int32_t *counts, int nframes, int max_candidates, hipStream_t s) {
     if (nframes < 1) return hipSuccess;
     const size_t lds = (size_t)4 * (max_candidates + 64) * sizeof(uint64_t);
+    // Two forms of the same replay.  The register form has the shorter dependent chain (a frame takes about
+    // 0.11 ms instead of 0.14) and is what small launches wait for; it issues more instructions, though, and a
+    // large launch runs next to the sync / LDPC kernels of the other half-batch, where the LDS form (which
+    // mostly waits) finishes earlier -- measured at 2048 frames per launch: 0.29 against 0.245 ms.
+    const int register_form = (max_candidates <= 128 && nframes <= 1024) ? 1 : 0;
     hipLaunchKernelGGL(ft8_heap_kernel, dim3((nframes + 3) / 4), dim3(256), lds, s,
-                       lists, list_counts, cands, counts, nframes, max_candidates);
+                       lists, list_counts, cands, counts, nframes, max_candidates, register_form);
     return hipGetLastError();
 }
