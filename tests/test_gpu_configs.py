@@ -116,3 +116,36 @@ def test_config5_oversubscribed_candidates(oracle):
         assert counts[f] == len(rc) and np.array_equal(cands[f, :counts[f]], rc)
         rdec, rn = oracle.subsystem(host_iq[f, 0], host_iq[f, 1], p)
         assert gn[f] == rn and gdec[f].tobytes() == rdec.tobytes()
+
+
+def test_non_overlapped_pipeline_gives_the_same_records(oracle):
+    """FT8GPU_OVERLAP=0: one launch per stage for the whole batch, no side stream, no chunked upload.
+    Same spot records as the default two-half pipeline on 1200 frames (device and host buffers)."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, hashlib, numpy as np
+sys.path.insert(0, '.')
+import torch, rtlsdr_ft8d_amd as ft8
+from rtlsdr_ft8d_amd import workload
+n = 1200
+_, tones = workload.message_pool()
+with ft8.Decoder(device=0, max_frames=n) as dec:
+    sig, _ = workload.frame_signals(0, n, 20, tones)
+    iq = torch.empty((n, 2, ft8.NSAMPLES), dtype=torch.float32, device='cuda')
+    dec.synth_frames(sig, n, 20, 1.0, workload.SEED_BASE, iq)
+    spots = torch.zeros((n, 1400), dtype=torch.uint8, device='cuda'); nres = torch.zeros((n,), dtype=torch.int32, device='cuda')
+    dec.decode_batch_dev(iq, n, spots, nres); dec.synchronize()
+    d, c = dec.decode_batch(iq.cpu().numpy())
+assert np.array_equal(c, nres.cpu().numpy()) and d.tobytes() == spots.cpu().numpy().tobytes()
+print('DIGEST', hashlib.sha256(spots.cpu().numpy().tobytes() + nres.cpu().numpy().tobytes()).hexdigest(), int(nres.sum()))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for overlap in ("1", "0"):
+        env = dict(os.environ, FT8GPU_OVERLAP=overlap)
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs.append([l for l in out.stdout.splitlines() if l.startswith("DIGEST")][-1])
+    assert outs[0] == outs[1] and int(outs[0].split()[-1]) > 8 * 1200
