@@ -101,7 +101,9 @@ void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lis
                 const uint32_t mid = cur[m];
                 const uint32_t up = b > 0 ? prev[m] : mid;                    // missing time neighbour: p - p = 0
                 const uint32_t dn = b + 1 < kNumBlocks ? next[m] : mid;
-                const uint32_t lnb = __shfl_up(mid, 1, 64), rnb = __shfl_down(mid, 1, 64);
+                // neighbouring column groups: whole-wave DPP shifts (one VALU move each, no LDS crossbar trip)
+                const uint32_t lnb = (uint32_t)__builtin_amdgcn_update_dpp((int)mid, (int)mid, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+                const uint32_t rnb = (uint32_t)__builtin_amdgcn_update_dpp((int)mid, (int)mid, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
                 const uint32_t left = lane > 0 ? lnb >> 24 : mid & 0xFFu;     // column 0 has no lower bin: p - p = 0
                 const uint32_t right = lane < 63 ? rnb & 0xFFu : 0u;          // column 255 is never addressed (f0 + tone <= 254)
                 const s16x2 m12 = bytes2(0, mid, 0x0c020c01u);                // (m1, m2): right of (m0, m1), left of (m2, m3)
