@@ -154,7 +154,7 @@ void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lis
         // row t0i of M0 / M3 / M6 is t' = t0 / t0 + 3 / t0 + 6; row t0i + k - 1 of MA is t' = t0 + k
         const int16_t *ma = s_map + (kOffA + t0i) * kMapPitch;
         const int16_t *m0 = s_map + (kOff0 + t0i) * kMapPitch, *m3 = s_map + (kOff3 + t0i) * kMapPitch, *m6 = s_map + (kOff6 + t0i) * kMapPitch;
-#pragma unroll 1
+#pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
             const int f0 = pass * 64 + lane;            // then freq_offset ascending
             const bool valid = f0 < kF0Count;
