@@ -24,6 +24,8 @@ sys.path.insert(0, ROOT)
 
 BYTES_PER_FRAME = 384000 + 1404          # IQ in + 50 spot records and the count out
 HBM_PEAK_GBPS = 8000.0                   # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_PEAK_GBPS = 6290.0              # same guide: measured copy peak (SURVEY.md 8(d) asks for both)
+FP32_VALU_PEAK = 157.3e12                # same guide: fp32 vector peak, flop/s (an FMA lane-instruction counts 2)
 FRAMES_DEFAULT = 4096                    # the PMC traffic figures in profiles/ were collected at this batch size
 
 
@@ -152,6 +154,8 @@ def main():
             "bound": "hbm", "kernel": dom.replace("_ms", ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": _pmc_traffic(dom.replace("_ms", ""), B, launches),
             "valu_busy_frac_pmc": _pmc_valu_busy(dom.replace("_ms", "")),
+            "valu_frac_of_fp32_peak_pmc": _pmc_valu_fraction(dom.replace("_ms", ""), B, launches, dom_ms / launches),
+            "frac_of_measured_copy_peak": round(achieved / HBM_COPY_PEAK_GBPS, 5),
             "kernel_ms": round(dom_ms, 4), "kernel_launches_per_step": launches,
             "kernel_ms_per_launch": round(dom_ms / launches, 4), "algorithmic_bytes_per_launch": BYTES_PER_FRAME * B // launches,
             "stage_ms": {k: round(v, 4) for k, v in stage_avg.items()}, "stage_ms_runs": timed_runs,
@@ -181,6 +185,22 @@ def _pmc_valu_busy(kernel):
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             return json.load(f).get(kernel, {}).get("valu_busy_frac")
     except (OSError, ValueError):
+        return None
+
+
+def _pmc_valu_fraction(kernel, frames, launches, ms_per_launch):
+    """SURVEY.md 8(d) "valu_fraction": VALU lane-operations per second of the dominant kernel over the fp32
+    vector peak.  SQ_INSTS_VALU (wave instructions per launch, committed PMC pass at this batch size) x 64
+    lanes / the live launch duration; one operation per lane-instruction (a packed or fused instruction
+    carries two, so this is a lower bound), against a peak that counts two per lane and clock."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            if json.load(f).get(kernel, {}).get("frames_per_launch") != frames // launches:
+                return None
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_counters_final.json")) as f:
+            insts = json.load(f)[kernel]["SQ_INSTS_VALU"]
+        return round(insts * 64 / (ms_per_launch * 1e-3) / FP32_VALU_PEAK, 4)
+    except (OSError, ValueError, KeyError):
         return None
 
 
