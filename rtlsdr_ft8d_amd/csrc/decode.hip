@@ -301,8 +301,11 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
         rvalid[rr] = d_tab.row_valid[rr][lane] != 0;
         rseven[rr] = d_tab.row_seven[rr][lane] != 0;
         rowidx[rr] = rvalid[rr] ? lane + 64 * rr : kRows - 1;
+        // the row masks are only needed by the exact check: the counting form uses them every iteration and
+        // keeps them in registers; the pipeline form runs that check on about one iteration in eight and
+        // fetches them from the (cache-resident) table then, which frees 12 VGPRs -- one more wave per SIMD
 #pragma unroll
-        for (int w = 0; w < 3; ++w) rmask[rr][w] = d_tab.rowmask[rr][lane][w];
+        for (int w = 0; w < 3; ++w) rmask[rr][w] = COUNT_ERRORS ? d_tab.rowmask[rr][lane][w] : 0ull;
     }
 
     // check-row tile: the 7th slot of a 6-member row is never written by an edge and must read 1.0f
@@ -398,7 +401,10 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
             int errors = 0;
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
-                const int par = (__popcll(B0 & rmask[rr][0]) + __popcll(B1 & rmask[rr][1]) + __popcll(B2 & rmask[rr][2])) & 1;
+                const uint64_t m0 = COUNT_ERRORS ? rmask[rr][0] : d_tab.rowmask[rr][lane][0];
+                const uint64_t m1 = COUNT_ERRORS ? rmask[rr][1] : d_tab.rowmask[rr][lane][1];
+                const uint64_t m2 = COUNT_ERRORS ? rmask[rr][2] : d_tab.rowmask[rr][lane][2];
+                const int par = (__popcll(B0 & m0) + __popcll(B1 & m1) + __popcll(B2 & m2)) & 1;
                 errors += __popcll(__ballot(rvalid[rr] && par));
             }
             if (COUNT_ERRORS) {
