@@ -418,6 +418,10 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
             }
         }
 
+        // The reference's last iteration still updates both message arrays, which nothing reads afterwards:
+        // the last hard decision has been taken and checked at this point.
+        if (iter + 1 >= max_iters) { iter = max_iters; break; }
+
         // ---- bits -> checks: toc[m][n_idx] = fast_tanh(-Tnm / 2) -------------------------------
         {
             f2 t[4];
