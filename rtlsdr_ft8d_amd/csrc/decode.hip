@@ -34,6 +34,7 @@
 #include "ft8_tables.h"
 #include "unpack_dev.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -335,10 +336,6 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
     //   hard decision: (u_r + ah[r][1]) + ah[r][2] = X[r].y + A[r].x
     // Which values share a register pair is free (every value is computed by the same operations in
     // the same order whatever its neighbour is); the LDS slot of every edge is a per-lane constant.
-    f2 A[3], B = { 0.0f, 0.0f };
-    float c2 = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) A[r] = f2{ 0.0f, 0.0f };
     float cwh[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) cwh[r] = cw[r] * -0.5f;
@@ -348,12 +345,38 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
     uint64_t B0 = 0, B1 = 0, B2 = 0;
     int iter = 0;
     bool fast_ok = !force_ieee_div;     // every state value is 0 or >= 2^-59 (true for the initial zeros)
-    for (; iter < max_iters; ++iter) {
-        // hard decision (tov = 0 in iteration 0) and Tnm / x for the lane's nine edges
+    // the nine row products of the previous iteration, in the pairing of the states they turn into
+    f2 PA[3] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } }, PB = { 0.0f, 0.0f };
+    float pc = 0.0f;
+
+    // One iteration up to the stores of toc, in the arithmetic form FAST selects (packed rcp/fma division and
+    // half-domain sums, or IEEE division and the reference's own domain).  The two forms are complete,
+    // separate instruction streams behind ONE wave-uniform branch per iteration: when they were chosen phase by
+    // phase, the values live across the three branch points cost 14 VGPRs and a wave of occupancy.
+    // Returns true when the loop ends here.
+    auto first_half = [&](auto fast_tag) -> bool {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        // ---- checks -> bits: tov[n][m_idx] = -2 * fast_atanh(product of the other toc of the row); the state
+        // kept is fast_atanh(...) itself, i.e. tov = -2 * state exactly (half domain).  No messages before
+        // the first iteration.
+        f2 A[3], B;
+        float c2;
+        if (iter > 0) {                                  // wave-uniform
+#pragma unroll
+            for (int r = 0; r < 3; ++r) A[r] = atanh_pair<FAST>(PA[r]);
+            B = atanh_pair<FAST>(PB);
+            c2 = atanh_one<FAST>(pc);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) A[r] = f2{ 0.0f, 0.0f };
+            B = f2{ 0.0f, 0.0f };
+            c2 = 0.0f;
+        }
+        // ---- hard decision and Tnm / x for the lane's nine edges
         // (lanes without a third variable compute on spare-row content and write to the spare row)
         f2 X[3], Y;
         float z;
-        if (fast_ok) {
+        if (FAST) {
             const f2 u01 = cwh01 + B;
             const float u2 = cwh[2] + c2;
             X[0] = f2{ u01.x, u01.x } + A[0];
@@ -386,7 +409,7 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
             B1 = __ballot(bit[1]);
             B2 = __ballot(bit[2]);
         }
-        if ((B0 | B1 | B2) == 0ull) break;              // all-zero word is prohibited
+        if ((B0 | B1 | B2) == 0ull) return true;        // all-zero word is prohibited
 
         // ldpc_check
         bool full_check = true;
@@ -410,42 +433,38 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
             if (COUNT_ERRORS) {
                 if (errors < min_errors) {
                     min_errors = errors;
-                    if (errors == 0) break;
+                    if (errors == 0) return true;
                 }
             } else if (errors == 0) {
                 min_errors = 0;
-                break;
+                return true;
             }
         }
-
         // The reference's last iteration still updates both message arrays, which nothing reads afterwards:
         // the last hard decision has been taken and checked at this point.
-        if (iter + 1 >= max_iters) { iter = max_iters; break; }
+        if (iter + 1 >= max_iters) { iter = max_iters; return true; }
 
-        // ---- bits -> checks: toc[m][n_idx] = fast_tanh(-Tnm / 2) -------------------------------
-        {
-            f2 t[4];
-            float tz;
-            if (fast_ok) {
+        // ---- bits -> checks: toc[m][n_idx] = fast_tanh(-Tnm / 2)
+        f2 t[4];
 #pragma unroll
-                for (int r = 0; r < 3; ++r) t[r] = tanh_pair<true>(X[r]);
-                t[3] = tanh_pair<true>(Y);
-                tz = tanh_one<true>(z);
-            } else {
+        for (int r = 0; r < 3; ++r) t[r] = tanh_pair<FAST>(X[r]);
+        t[3] = tanh_pair<FAST>(Y);
+        const float tz = tanh_one<FAST>(z);
 #pragma unroll
-                for (int r = 0; r < 3; ++r) t[r] = tanh_pair<false>(X[r]);
-                t[3] = tanh_pair<false>(Y);
-                tz = tanh_one<false>(z);
-            }
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                toc[slot[3 * r + 1]] = t[r].x;
-                toc[slot[3 * r + 2]] = t[r].y;
-            }
-            toc[slot[0]] = t[3].x;
-            toc[slot[3]] = t[3].y;
-            toc[slot[6]] = tz;
+        for (int r = 0; r < 3; ++r) {
+            toc[slot[3 * r + 1]] = t[r].x;
+            toc[slot[3 * r + 2]] = t[r].y;
         }
+        toc[slot[0]] = t[3].x;
+        toc[slot[3]] = t[3].y;
+        toc[slot[6]] = tz;
+        return false;
+    };
+
+    for (;; ++iter) {
+        if (iter >= max_iters) break;                    // (max_iters >= 1 is checked by the API; the loop leaves through first_half)
+        const bool stop = fast_ok ? first_half(std::true_type{}) : first_half(std::false_type{});
+        if (stop) break;
         wave_lds_sync();
 
         // ---- check rows: ordered products that skip one member, for all members ---------------
@@ -468,14 +487,12 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
         }
         wave_lds_sync();
 
-        // ---- checks -> bits: tov[n][m_idx] = -2 * fast_atanh(product of the other toc of the row); the
-        // state kept is fast_atanh(...) itself, i.e. tov = -2 * state exactly (half domain) -------------
-        f2 PA[3], PB;
+        // ---- the lane's nine products come back; they become messages at the top of the next iteration -------
 #pragma unroll
         for (int r = 0; r < 2; ++r) PA[r] = f2{ toc[slot[3 * r + 2]], toc[slot[3 * r + 1]] };
         PB = f2{ toc[slot[0]], toc[slot[3]] };
         PA[2] = f2{ toc[slot[8]], toc[slot[7]] };
-        const float pc = toc[slot[6]];
+        pc = toc[slot[6]];
         // Lanes without a third variable run these three edges on whatever the spare row holds; nothing
         // they compute leaves the spare row or their own registers (their decision bit is masked), so the
         // guard ignores them.
@@ -497,18 +514,7 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
             for (int r = 0; r < 2; ++r) gmin = min(gmin, min(guard_key(PA[r].x), guard_key(PA[r].y)));
             guard_ok = __all(gmin >= kGuardMin);
         }
-        fast_ok = guard_ok && !force_ieee_div;                        // wave-uniform; also governs the next tanh phase
-        if (fast_ok) {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) A[r] = atanh_pair<true>(PA[r]);
-            B = atanh_pair<true>(PB);
-            c2 = atanh_one<true>(pc);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) A[r] = atanh_pair<false>(PA[r]);
-            B = atanh_pair<false>(PB);
-            c2 = atanh_one<false>(pc);
-        }
+        fast_ok = guard_ok && !force_ieee_div;                        // wave-uniform; governs the whole next iteration
         // (the next iteration's toc stores hit only this lane's own slots; LDS is in order per wave)
     }
 
