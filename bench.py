@@ -79,7 +79,7 @@ def main():
     _, pool_tones = workload.message_pool()
     sig, _ = workload.frame_signals(lo, B, args.nsig, pool_tones, snr_range=tuple(args.snr))
     iq = torch.empty((B, 2, ft8.NSAMPLES), dtype=torch.float32, device=dev)
-    dec.synth_frames(sig, B, args.nsig, 1.0, workload.SEED_BASE + lo, iq)
+    dec.synth_frames(sig, B, args.nsig, 1.0, workload.SEED_BASE, iq, first_frame=lo)
     # spot records: two buffers per rank; the exchange of step k (one asynchronous RCCL all-gather of
     # records + counts) runs under the kernels of step k + 1 and is drained inside the timed region
     exch = workload.SpotExchange(B, world, dev, collective=use_dist)

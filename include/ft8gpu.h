@@ -10,11 +10,9 @@
  *   A batch is `nframes` such frames back to back: iq[nframes][2][48000].
  *   waterfall = uint8 mag[92][2][2][256] (block, time_sub, freq_sub, bin) = 94208 bytes per frame.
  *
- * Environment switches (read once): FT8GPU_DEVICE=<n> GPU used by the drop-in ft8_subsystem (default 0);
- * FT8GPU_OVERLAP=0 disables the two-half overlapped pipeline for batches >= 512 frames;
- * FT8GPU_FORCE_IEEE_DIV=1 makes the LDPC kernel use the compiler's IEEE division everywhere (test hook);
- * FT8GPU_DECODE_PIPELINE_FORM=1 makes ft8gpu_decode_candidates run the form of the LDPC kernel that
- * ft8gpu_decode_batch uses (no exact error count: ldpc_errors is 0 or 83; test hook).
+ * Environment: FT8GPU_DEVICE=<n> GPU used by the drop-in ft8_subsystem (default 0).  The test hooks are
+ * per-context flags (ft8gpu_set_debug_flags); FT8GPU_OVERLAP=0, FT8GPU_FORCE_IEEE_DIV=1 and
+ * FT8GPU_DECODE_PIPELINE_FORM=1 only set their initial value for contexts created afterwards.
  */
 #ifndef FT8GPU_H
 #define FT8GPU_H
@@ -110,13 +108,24 @@ typedef struct {
 
 /* Creates a decoder context on GPU `device` with persistent buffers for up to `max_frames` frames
  * (larger batches are processed in chunks of max_frames).  `params` may be NULL (reference defaults
- * 10 / 120 / 20).  Returns 0 on success.  A context owns its intermediate buffers and is meant for one
- * host thread at a time; use one context per thread / per GPU (contexts are independent, unlike the
- * reference's process-global FFTW state, rtlsdr_ft8d.c:57-60). */
+ * 10 / 120 / 20).  Returns 0 on success.  A context owns its intermediate buffers; every entry point
+ * holds the context's mutex, so two host threads calling into ONE context serialise (use one context
+ * per thread / per GPU for concurrency: contexts are independent, unlike the reference's process-global
+ * FFTW state, rtlsdr_ft8d.c:57-60).  Entry points make the context's GPU current for their duration and
+ * restore the caller's current device before returning. */
 int  ft8gpu_create(ft8gpu_ctx **out, int device, int max_frames, const ft8gpu_params *params);
 void ft8gpu_destroy(ft8gpu_ctx *ctx);
-/* Use an existing hipStream_t (passed as void*) for all work of this context; NULL = own stream. */
+/* Use an existing hipStream_t (passed as void*) for all work of this context.  NULL = the context
+ * creates its own non-blocking stream; FT8GPU_STREAM_LEGACY (= hipStreamLegacy) selects the legacy
+ * null stream explicitly. */
 int  ft8gpu_set_stream(ft8gpu_ctx *ctx, void *hip_stream);
+#define FT8GPU_STREAM_LEGACY ((void *)1)
+/* test hooks, per context (any combination; 0 = product behaviour) */
+#define FT8GPU_DBG_FORCE_IEEE_DIV 1u  /* LDPC kernel: the compiler's IEEE division everywhere (the guard's fallback path) */
+#define FT8GPU_DBG_PIPELINE_FORM  2u  /* ft8gpu_decode_candidates runs the form of the LDPC kernel ft8gpu_decode_batch
+                                         uses (no exact error count: ldpc_errors is 0 or 83) */
+#define FT8GPU_DBG_NO_OVERLAP     4u  /* one launch per stage for the whole batch: no two-half overlap, no chunked upload */
+int  ft8gpu_set_debug_flags(ft8gpu_ctx *ctx, unsigned flags);
 int  ft8gpu_set_params(ft8gpu_ctx *ctx, const ft8gpu_params *params);
 int  ft8gpu_enable_timing(ft8gpu_ctx *ctx, int on);
 int  ft8gpu_get_timings(ft8gpu_ctx *ctx, ft8gpu_timings *out, int32_t *nruns);
@@ -134,6 +143,21 @@ int  ft8gpu_device_count(void);
  * in a frame -> the surplus is dropped (reference: infinite loop); missing tokens -> "(null)". */
 int ft8gpu_decode_batch(ft8gpu_ctx *ctx, const float *iq, int nframes,
                         struct decoder_results *decodes, int32_t *n_results, int flags);
+
+/* ---- the same across several GPUs of one node, for a plain C caller ------
+ * ctxs[0..ndev): one context per GPU (normally ft8gpu_create(&ctxs[g], g, ...); several contexts on one
+ * GPU are legal).  Frames are independent, so the batch is cut into ndev contiguous shards (shard g =
+ * frames [g*n/ndev, (g+1)*n/ndev)), each decoded by its own host thread on its own context, and every
+ * shard's records land directly at their frame offsets in the caller's HOST arrays -- the gather of the
+ * 1 404 B/frame spot records is that placement; no collective is needed when the list is consumed on
+ * the host, as the daemon does.  iq / decodes / n_results are host memory (FT8GPU_HOST_PTRS layout of
+ * ft8gpu_decode_batch).  Returns 0, or -1 with ft8gpu_last_error() naming the failing shard. */
+int ft8gpu_decode_batch_multi(ft8gpu_ctx *const *ctxs, int ndev, const float *iq, int nframes,
+                              struct decoder_results *decodes, int32_t *n_results);
+/* Device-resident form: shard g's frames already sit in HBM of ctxs[g]'s GPU (iq_dev[g]: [nframes_dev[g]][2][48000],
+ * e.g. synthesised or decimated there); records are gathered into the host arrays in shard order. */
+int ft8gpu_decode_batch_multi_dev(ft8gpu_ctx *const *ctxs, int ndev, const float *const *iq_dev,
+                                  const int *nframes_dev, struct decoder_results *decodes, int32_t *n_results);
 
 /* ---- stage entries (same data, stage by stage; used by the parity tests) --------------------- */
 /* rtlsdr_ft8d.c:1395-1435: window, 184 FFTs, log-magnitude, quantise.  mag: [nframes][94208] */
@@ -174,6 +198,12 @@ typedef struct {
  * signals: host array [nframes][nsig_per_frame]; iq_dev: device pointer [nframes][2][48000]. */
 int ft8gpu_synth_frames(ft8gpu_ctx *ctx, const ft8gpu_synth_signal *signals, int nframes,
                         int nsig_per_frame, float noise_sigma, uint64_t seed, float *iq_dev);
+/* The same for a shard of a larger job: frame k of this call is global frame first_frame + k, and the
+ * noise of a frame depends on (seed, global frame index) only -- any partition of the job over ranks,
+ * GPUs or calls synthesises the same frames.  ft8gpu_synth_frames == first_frame 0. */
+int ft8gpu_synth_frames_at(ft8gpu_ctx *ctx, const ft8gpu_synth_signal *signals, int nframes,
+                           int nsig_per_frame, float noise_sigma, uint64_t seed, uint64_t first_frame,
+                           float *iq_dev);
 
 /* ---- RX front end: rtlsdr_callback(), rtlsdr_ft8d.c:76-202 ------------
  * Whole raw RTL-SDR captures (unsigned 8-bit I,Q interleaved at 2.4 Msps) -> the 15 s / ~3200 sps
@@ -213,11 +243,12 @@ int ft8gpu_pskreporter_datagrams(ft8gpu_ctx *ctx, const struct decoder_results *
 int ft8gpu_format_spots(const struct decoder_results *decodes, int32_t n_results, uint32_t dial_freq,
                         int year, int month, int mday, int hour, int minute, char *out, size_t cap);
 
-/* device memory helpers so that a plain C caller needs no HIP headers */
-void *ft8gpu_dev_alloc(size_t bytes);
-void  ft8gpu_dev_free(void *p);
-int   ft8gpu_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
-int   ft8gpu_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+/* device memory helpers so that a plain C caller needs no HIP headers; they act on the context's GPU
+ * (whatever device is current in the calling thread) and order after the context's enqueued work */
+void *ft8gpu_dev_alloc(ft8gpu_ctx *ctx, size_t bytes);
+void  ft8gpu_dev_free(ft8gpu_ctx *ctx, void *p);
+int   ft8gpu_memcpy_h2d(ft8gpu_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int   ft8gpu_memcpy_d2h(ft8gpu_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 
 /* ---- drop-in symbols of the reference (rtlsdr_ft8d.h:155-156, :164) --------------------------
  * Link rtlsdr_ft8d.c against libft8gpu.so instead of its own ft8_subsystem/initFFTW/freeFFTW

@@ -139,6 +139,11 @@ void ft8o_fft1024_f64(const double *re_in, const double *im_in, double *re, doub
 uint8_t ft8o_quantise(float mag2) {
     /* :1416  NFFT*NFFT is uint32_t 1048576, converted to float for the division */
     float db = 10.0f * log10f(1E-12f + mag2 * 4.0f / (float)((uint32_t)FT8O_NFFT * (uint32_t)FT8O_NFFT));
+    /* Fence: for non-finite |X|^2 (inf / NaN / absurdly large samples) the reference's (int) conversion at
+     * :1425 is undefined behaviour: x86 yields INT_MIN -> 0, ARM (the reference's Raspberry Pi targets)
+     * saturates -> 255 for +inf and 0 for NaN.  Defined here as the saturating result. */
+    if (isnan(db)) return 0;
+    if (isinf(db)) return (uint8_t)(db > 0 ? 255 : 0);
     int scaled = (int)(2 * db + 240);                                   /* :1425 */
     return (uint8_t)((scaled < 0) ? 0 : ((scaled > 255) ? 255 : scaled)); /* :1427 */
 }

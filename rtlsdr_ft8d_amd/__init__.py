@@ -48,6 +48,8 @@ class ReportInfo(C.Structure):
 
 
 DATAGRAM_STRIDE = 1408
+STREAM_LEGACY = 1                       # FT8GPU_STREAM_LEGACY (= hipStreamLegacy): the legacy null stream, explicitly
+DBG_FORCE_IEEE_DIV, DBG_PIPELINE_FORM, DBG_NO_OVERLAP = 1, 2, 4      # FT8GPU_DBG_* test hooks (per context)
 
 
 class Ft8GpuError(RuntimeError):
@@ -59,7 +61,9 @@ ABI_SYMBOLS = [
     "ft8gpu_get_timings", "ft8gpu_synchronize", "ft8gpu_last_error", "ft8gpu_device_count",
     "ft8gpu_decode_batch", "ft8gpu_waterfall", "ft8gpu_find_sync", "ft8gpu_score_map",
     "ft8gpu_decode_candidates", "ft8gpu_collect_spots", "ft8gpu_pack77_std", "ft8gpu_encode",
-    "ft8gpu_synth_frames", "ft8gpu_rx_decimate", "ft8gpu_pskreporter_datagrams", "ft8gpu_format_spots", "ft8gpu_dev_alloc", "ft8gpu_dev_free", "ft8gpu_memcpy_h2d", "ft8gpu_memcpy_d2h",
+    "ft8gpu_synth_frames", "ft8gpu_synth_frames_at", "ft8gpu_rx_decimate", "ft8gpu_pskreporter_datagrams", "ft8gpu_format_spots",
+    "ft8gpu_dev_alloc", "ft8gpu_dev_free", "ft8gpu_memcpy_h2d", "ft8gpu_memcpy_d2h",
+    "ft8gpu_set_debug_flags", "ft8gpu_decode_batch_multi", "ft8gpu_decode_batch_multi_dev",
     "initFFTW", "freeFFTW", "ft8_subsystem", "ft8gpu_read_raw_iq", "ft8gpu_read_c2", "ft8gpu_write_raw_iq",
 ]
 
@@ -105,15 +109,19 @@ def load_library():
     L.ft8gpu_encode.argtypes = [vp, vp]
     L.ft8gpu_encode.restype = None
     L.ft8gpu_synth_frames.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, C.c_uint64, vp]
+    L.ft8gpu_synth_frames_at.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint64, vp]
+    L.ft8gpu_set_debug_flags.argtypes = [vp, C.c_uint]
+    L.ft8gpu_decode_batch_multi.argtypes = [C.POINTER(vp), C.c_int, vp, C.c_int, vp, vp]
+    L.ft8gpu_decode_batch_multi_dev.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp), C.POINTER(C.c_int), vp, vp]
     L.ft8gpu_rx_decimate.argtypes = [vp, vp, C.c_int, C.c_size_t, vp, C.c_int, C.c_int]
     L.ft8gpu_pskreporter_datagrams.argtypes = [vp, vp, vp, C.c_int, C.POINTER(ReportInfo), vp, vp, vp, C.c_int]
     L.ft8gpu_format_spots.argtypes = [vp, C.c_int32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t]
-    L.ft8gpu_dev_alloc.argtypes = [C.c_size_t]
+    L.ft8gpu_dev_alloc.argtypes = [vp, C.c_size_t]
     L.ft8gpu_dev_alloc.restype = vp
-    L.ft8gpu_dev_free.argtypes = [vp]
+    L.ft8gpu_dev_free.argtypes = [vp, vp]
     L.ft8gpu_dev_free.restype = None
-    L.ft8gpu_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
-    L.ft8gpu_memcpy_d2h.argtypes = [vp, vp, C.c_size_t]
+    L.ft8gpu_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+    L.ft8gpu_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
     L.initFFTW.restype = None
     L.freeFFTW.restype = None
     L.ft8_subsystem.argtypes = [vp, vp, C.c_uint32, vp, i32p]
@@ -194,7 +202,16 @@ class Decoder:
         self.params = p
 
     def set_stream(self, stream_handle):
-        _check(self.lib.ft8gpu_set_stream(self.h, C.c_void_p(stream_handle or None)))
+        """None: the context creates its own stream.  An integer is a hipStream_t; 0 (what torch reports for its
+        default stream) is passed as hipStreamLegacy, the explicit name of the null stream."""
+        if stream_handle is None:
+            h = None
+        else:
+            h = int(stream_handle) or STREAM_LEGACY
+        _check(self.lib.ft8gpu_set_stream(self.h, C.c_void_p(h)))
+
+    def set_debug_flags(self, flags):
+        _check(self.lib.ft8gpu_set_debug_flags(self.h, int(flags)))
 
     def enable_timing(self, on=True):
         _check(self.lib.ft8gpu_enable_timing(self.h, int(on)))
@@ -305,11 +322,59 @@ class Decoder:
                                                      None if unixtimes_dev is None else _ptr(unixtimes_dev),
                                                      _ptr(datagrams_dev), _ptr(lengths_dev), DEVICE_PTRS))
 
-    def synth_frames(self, signals, nframes, nsig, noise_sigma, seed, iq_dev):
+    def synth_frames(self, signals, nframes, nsig, noise_sigma, seed, iq_dev, first_frame=0):
+        """frame k of the call is global frame first_frame + k; its noise depends on (seed, global index) only"""
         signals = np.ascontiguousarray(signals)
         assert signals.dtype == SIGNAL_DTYPE and signals.size == nframes * nsig
-        _check(self.lib.ft8gpu_synth_frames(self.h, signals.ctypes.data, nframes, nsig, float(noise_sigma),
-                                            int(seed), _ptr(iq_dev)))
+        _check(self.lib.ft8gpu_synth_frames_at(self.h, signals.ctypes.data, nframes, nsig, float(noise_sigma),
+                                               int(seed), int(first_frame), _ptr(iq_dev)))
+
+    # ---- device memory helpers of the C ABI (a plain C caller has no HIP headers) ---------------
+    def dev_alloc(self, nbytes):
+        p = self.lib.ft8gpu_dev_alloc(self.h, nbytes)
+        if not p:
+            raise Ft8GpuError(self.lib.ft8gpu_last_error().decode(errors="replace"))
+        return p
+
+    def dev_free(self, p):
+        self.lib.ft8gpu_dev_free(self.h, C.c_void_p(p))
+
+    def memcpy_h2d(self, dst_dev, src):
+        src = np.ascontiguousarray(src)
+        _check(self.lib.ft8gpu_memcpy_h2d(self.h, C.c_void_p(_ptr(dst_dev)), src.ctypes.data, src.nbytes))
+
+    def memcpy_d2h(self, dst, src_dev):
+        assert dst.flags["C_CONTIGUOUS"]
+        _check(self.lib.ft8gpu_memcpy_d2h(self.h, dst.ctypes.data, C.c_void_p(_ptr(src_dev)), dst.nbytes))
+
+
+def decode_batch_multi(decoders, iq, decodes=None):
+    """ft8gpu_decode_batch_multi: host frames [B][2][48000] cut into len(decoders) contiguous shards, one host
+    thread and one context (normally one GPU) per shard, records gathered in the caller's host arrays"""
+    iq = np.ascontiguousarray(iq, np.float32)
+    B = iq.shape[0]
+    assert iq.shape[1:] == (2, NSAMPLES)
+    if decodes is None:
+        decodes = np.zeros((B, MAX_MESSAGES), RESULT_DTYPE)
+    n = np.zeros(B, np.int32)
+    hs = (C.c_void_p * len(decoders))(*[d.h for d in decoders])
+    _check(load_library().ft8gpu_decode_batch_multi(hs, len(decoders), iq.ctypes.data, B, decodes.ctypes.data, n.ctypes.data))
+    return decodes, n
+
+
+def decode_batch_multi_dev(decoders, iq_devs, nframes, decodes=None):
+    """ft8gpu_decode_batch_multi_dev: shard g's frames are resident on decoders[g]'s GPU (iq_devs[g]: device
+    pointer / tensor, nframes[g] frames); records gathered on the host in shard order"""
+    total = int(sum(nframes))
+    if decodes is None:
+        decodes = np.zeros((total, MAX_MESSAGES), RESULT_DTYPE)
+    n = np.zeros(total, np.int32)
+    k = len(decoders)
+    hs = (C.c_void_p * k)(*[d.h for d in decoders])
+    ps = (C.c_void_p * k)(*[_ptr(p) if p is not None else None for p in iq_devs])
+    ns = (C.c_int * k)(*[int(x) for x in nframes])
+    _check(load_library().ft8gpu_decode_batch_multi_dev(hs, k, ps, ns, decodes.ctypes.data, n.ctypes.data))
+    return decodes, n
 
 
 def format_spots(decodes, n_results, dial_freq, year, month, mday, hour, minute):

@@ -602,10 +602,9 @@ hipError_t decode_tables_init(hipStream_t s) {
 
 hipError_t launch_decode(const uint8_t *mag, const ft8gpu_candidate *cands, const int32_t *counts,
                          ft8gpu_decode_status *status, int nframes, int max_candidates, int ldpc_iters,
-                         bool count_errors, hipStream_t s) {
-    // FT8GPU_FORCE_IEEE_DIV=1 routes every BP division through the compiler's IEEE expansion (the
-    // path the guard falls back to); used by the parity tests to cover that path
-    static const int force_ieee_div = [] { const char *e = getenv("FT8GPU_FORCE_IEEE_DIV"); return (e && e[0] == '1') ? 1 : 0; }();
+                         bool count_errors, int force_ieee_div, hipStream_t s) {
+    // force_ieee_div (FT8GPU_DBG_FORCE_IEEE_DIV) routes every BP division through the compiler's IEEE
+    // expansion (the path the guard falls back to); used by the parity tests to cover that path
     if (nframes < 1) return hipSuccess;
     const unsigned bpf = (unsigned)(max_candidates + 3) / 4;                  // blocks (of 4 candidate waves) per frame
     const unsigned long long nblocks = (unsigned long long)nframes * bpf;

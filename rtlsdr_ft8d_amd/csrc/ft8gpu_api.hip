@@ -9,6 +9,10 @@
 #include <stdlib.h>
 #include <string.h>
 #include <float.h>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
 
 namespace {
 
@@ -67,7 +71,7 @@ int build_tables(Ft8Tables *t) {
                 return fail("host log10f is not monotone around quantiser threshold %d", k);
         }
     }
-    for (int k = 256; k < 260; k++) t->qthr[k] = INFINITY;
+    for (int k = 256; k < 260; k++) t->qthr[k] = NAN;       // `y >= qthr[256]` must be false for every y, +inf included
     // sampled global check of the threshold form against the direct expression
     uint64_t s = 0x243F6A8885A308D3ull;
     for (int it = 0; it < 200000; it++) {
@@ -100,7 +104,8 @@ struct ft8gpu_ctx {
     hipStream_t side = nullptr;            // carries the serial kernels (heap, spots) of one half-batch
                                            // while the main stream works on the other half
     hipEvent_t dep[6]{};                   // cross-stream dependencies (no timing)
-    bool overlap = true;
+    std::mutex mu;                         // every entry point holds it: concurrent callers of one context serialise
+    unsigned debug_flags = 0;              // FT8GPU_DBG_* (test hooks, per context)
     hipStream_t copy = nullptr;            // host-buffer calls: uploads chunk k+1 while chunk k is decoded
     static constexpr int kCopyEvents = 4;
     hipEvent_t copied[kCopyEvents]{};
@@ -147,6 +152,20 @@ int check_params(const ft8gpu_params *p) {
     return 0;
 }
 
+// Every ABI entry that touches a context holds its mutex (two host threads on one context serialise instead
+// of racing on the staging buffers and the timing ring) and runs with the context's GPU current, restoring
+// the caller's current device on the way out.
+struct Entry {
+    std::unique_lock<std::mutex> lock;
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit Entry(ft8gpu_ctx *c) : lock(c->mu) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != c->device) err = hipSetDevice(c->device); else prev = -1;
+    }
+    ~Entry() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 struct StageTimer {
     ft8gpu_ctx *c;
     explicit StageTimer(ft8gpu_ctx *ctx) : c(ctx) {}
@@ -158,6 +177,8 @@ struct StageTimer {
         c->runs++;
     }
 };
+
+inline int force_ieee(const ft8gpu_ctx *c) { return (c->debug_flags & FT8GPU_DBG_FORCE_IEEE_DIV) ? 1 : 0; }
 
 float elapsed(hipEvent_t a, hipEvent_t b) {
     float ms = 0.f;
@@ -206,11 +227,11 @@ int run_pipeline_overlapped(ft8gpu_ctx *c, const float *d_iq, int n, struct deco
     // main stream: decode(H0), decode(H1), spots(H1)
     HIP_TRY(hipStreamWaitEvent(c->stream, E[2], 0));
     t.mark(3);
-    HIP_TRY(launch_decode(c->d_mag, c->d_cands, c->d_counts, c->d_status, n0, mc, p.ldpc_iters, false, c->stream));
+    HIP_TRY(launch_decode(c->d_mag, c->d_cands, c->d_counts, c->d_status, n0, mc, p.ldpc_iters, false, force_ieee(c), c->stream));
     t.mark(4);
     HIP_TRY(hipEventRecord(E[4], c->stream));
     HIP_TRY(hipStreamWaitEvent(c->stream, E[3], 0));
-    HIP_TRY(launch_decode(mag1, cands1, counts1, st1, n1, mc, p.ldpc_iters, false, c->stream));
+    HIP_TRY(launch_decode(mag1, cands1, counts1, st1, n1, mc, p.ldpc_iters, false, force_ieee(c), c->stream));
     t.mark(5);
     // side stream: spots(H0) while decode(H1) runs
     HIP_TRY(hipStreamWaitEvent(c->side, E[4], 0));
@@ -228,7 +249,7 @@ int run_pipeline_overlapped(ft8gpu_ctx *c, const float *d_iq, int n, struct deco
 
 // the pipeline on device pointers; all intermediates in the context's HBM buffers
 int run_pipeline(ft8gpu_ctx *c, const float *d_iq, int n, struct decoder_results *d_dec, int32_t *d_nres) {
-    if (c->overlap && n >= 512) return run_pipeline_overlapped(c, d_iq, n, d_dec, d_nres);
+    if (!(c->debug_flags & FT8GPU_DBG_NO_OVERLAP) && n >= 512) return run_pipeline_overlapped(c, d_iq, n, d_dec, d_nres);
     StageTimer t(c);
     const ft8gpu_params &p = c->params;
     t.mark(0);
@@ -238,7 +259,7 @@ int run_pipeline(ft8gpu_ctx *c, const float *d_iq, int n, struct decoder_results
     t.mark(2);
     HIP_TRY(launch_heap(c->d_lists, c->d_list_counts, c->d_cands, c->d_counts, n, p.max_candidates, c->stream));
     t.mark(3);
-    HIP_TRY(launch_decode(c->d_mag, c->d_cands, c->d_counts, c->d_status, n, p.max_candidates, p.ldpc_iters, false, c->stream));
+    HIP_TRY(launch_decode(c->d_mag, c->d_cands, c->d_counts, c->d_status, n, p.max_candidates, p.ldpc_iters, false, force_ieee(c), c->stream));
     t.mark(4);
     HIP_TRY(launch_spots(c->d_cands, c->d_counts, c->d_status, n, p.max_candidates, p.min_score, d_dec, d_nres, c->stream));
     t.mark(5);
@@ -247,6 +268,12 @@ int run_pipeline(ft8gpu_ctx *c, const float *d_iq, int n, struct decoder_results
 }
 
 }  // namespace
+
+#define CHECK_COMMON(c, n)                                                              \
+    if (!(c)) return fail("ctx is NULL");                                               \
+    if ((n) < 0) return fail("nframes < 0");                                            \
+    Entry entry_(c);                                                                    \
+    HIP_TRY(entry_.err);
 
 extern "C" {
 
@@ -270,7 +297,10 @@ static int create_body(ft8gpu_ctx *c) {
     for (auto &e : c->dep) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
     for (auto &e : c->copied) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    { const char *e = getenv("FT8GPU_OVERLAP"); c->overlap = !(e && e[0] == '0'); }
+    // process-wide defaults of the per-context test hooks (ft8gpu_set_debug_flags overrides them)
+    { const char *e = getenv("FT8GPU_OVERLAP"); if (e && e[0] == '0') c->debug_flags |= FT8GPU_DBG_NO_OVERLAP; }
+    { const char *e = getenv("FT8GPU_FORCE_IEEE_DIV"); if (e && e[0] == '1') c->debug_flags |= FT8GPU_DBG_FORCE_IEEE_DIV; }
+    { const char *e = getenv("FT8GPU_DECODE_PIPELINE_FORM"); if (e && e[0] == '1') c->debug_flags |= FT8GPU_DBG_PIPELINE_FORM; }
 
     Ft8Tables *h = (Ft8Tables *)malloc(sizeof(Ft8Tables));
     if (!h) return fail("out of host memory");
@@ -301,24 +331,31 @@ int ft8gpu_create(ft8gpu_ctx **out, int device, int max_frames, const ft8gpu_par
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail("ft8gpu_create: device %d not present (%d visible)", device, ndev);
+    int prev = -1;
+    (void)hipGetDevice(&prev);
     HIP_TRY(hipSetDevice(device));
     ft8gpu_ctx *c = new ft8gpu_ctx();
     c->device = device;
     c->max_frames = max_frames;
     if (params) c->params = *params;
-    if (create_body(c)) {
+    const int rc = create_body(c);
+    if (rc) {
         char keep[sizeof g_err];
         memcpy(keep, g_err, sizeof keep);          // ft8gpu_destroy must not clobber the reason
         ft8gpu_destroy(c);
         memcpy(g_err, keep, sizeof keep);
-        return -1;
+    } else {
+        *out = c;
     }
-    *out = c;
-    return 0;
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);     // the caller's current device is left as it was
+    return rc ? -1 : 0;
 }
 
 void ft8gpu_destroy(ft8gpu_ctx *c) {
     if (!c) return;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{ prev };
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = { c->d_tab, c->d_iq, c->d_mag, c->d_lists, c->d_list_counts, c->d_cands, c->d_counts,
@@ -337,9 +374,11 @@ void ft8gpu_destroy(ft8gpu_ctx *c) {
     delete c;
 }
 
+// hip_stream: NULL = the context creates its own (non-blocking) stream; any other value is used as given,
+// including hipStreamLegacy ((hipStream_t)1, FT8GPU_STREAM_LEGACY) for the legacy null stream and
+// hipStreamPerThread ((hipStream_t)2).
 int ft8gpu_set_stream(ft8gpu_ctx *c, void *hip_stream) {
-    if (!c) return fail("ctx is NULL");
-    HIP_TRY(hipSetDevice(c->device));
+    CHECK_COMMON(c, 0);
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipStreamSynchronize(c->side));
     if (c->own_stream) { (void)hipStreamDestroy(c->stream); c->own_stream = false; }
@@ -351,7 +390,7 @@ int ft8gpu_set_stream(ft8gpu_ctx *c, void *hip_stream) {
 int ft8gpu_set_params(ft8gpu_ctx *c, const ft8gpu_params *p) {
     if (!c || !p) return fail("NULL argument");
     if (check_params(p)) return -1;
-    HIP_TRY(hipSetDevice(c->device));
+    CHECK_COMMON(c, 0);
     if (p->max_candidates > c->cap_candidates) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (alloc_candidate_buffers(c, p->max_candidates)) return -1;
@@ -360,8 +399,15 @@ int ft8gpu_set_params(ft8gpu_ctx *c, const ft8gpu_params *p) {
     return 0;
 }
 
+int ft8gpu_set_debug_flags(ft8gpu_ctx *c, unsigned flags) {
+    CHECK_COMMON(c, 0);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->debug_flags = flags;
+    return 0;
+}
+
 int ft8gpu_enable_timing(ft8gpu_ctx *c, int on) {
-    if (!c) return fail("ctx is NULL");
+    CHECK_COMMON(c, 0);
     c->timing = on != 0;
     c->runs = 0;
     return 0;
@@ -370,8 +416,8 @@ int ft8gpu_enable_timing(ft8gpu_ctx *c, int on) {
 // mean over the (up to 32 most recent) pipeline runs recorded since ft8gpu_enable_timing(ctx, 1)
 int ft8gpu_get_timings(ft8gpu_ctx *c, ft8gpu_timings *out, int32_t *nruns) {
     if (!c || !out) return fail("NULL argument");
+    CHECK_COMMON(c, 0);
     if (!c->timing || c->runs == 0) return fail("no timed pipeline run recorded");
-    HIP_TRY(hipSetDevice(c->device));
     const int n = c->runs < ft8gpu_ctx::kTimingSlots ? (int)c->runs : ft8gpu_ctx::kTimingSlots;
     double acc[6] = { 0, 0, 0, 0, 0, 0 };
     int launches = 1;
@@ -406,22 +452,39 @@ int ft8gpu_get_timings(ft8gpu_ctx *c, ft8gpu_timings *out, int32_t *nruns) {
 }
 
 int ft8gpu_synchronize(ft8gpu_ctx *c) {
-    if (!c) return fail("ctx is NULL");
+    CHECK_COMMON(c, 0);
     HIP_TRY(hipStreamSynchronize(c->stream));                // the main stream joins the side stream at the end of a run
     return 0;
 }
 
-void *ft8gpu_dev_alloc(size_t bytes) { void *p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) { fail("hipMalloc(%zu) failed", bytes); return nullptr; } return p; }
-void ft8gpu_dev_free(void *p) { if (p) (void)hipFree(p); }
-int ft8gpu_memcpy_h2d(void *d, const void *s, size_t n) { HIP_TRY(hipMemcpy(d, s, n, hipMemcpyHostToDevice)); return 0; }
-int ft8gpu_memcpy_d2h(void *d, const void *s, size_t n) { HIP_TRY(hipMemcpy(d, s, n, hipMemcpyDeviceToHost)); return 0; }
+// device memory helpers: they act on the context's GPU (not on whatever device happens to be current)
+void *ft8gpu_dev_alloc(ft8gpu_ctx *c, size_t bytes) {
+    if (!c) { fail("ctx is NULL"); return nullptr; }
+    Entry entry_(c);
+    void *p = nullptr;
+    if (entry_.err != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) { fail("hipMalloc(%zu) on device %d failed", bytes, c->device); return nullptr; }
+    return p;
+}
+void ft8gpu_dev_free(ft8gpu_ctx *c, void *p) {
+    if (!c || !p) return;
+    Entry entry_(c);
+    (void)hipFree(p);
+}
+int ft8gpu_memcpy_h2d(ft8gpu_ctx *c, void *d, const void *s, size_t n) {
+    CHECK_COMMON(c, 0);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(d, s, n, hipMemcpyHostToDevice));
+    return 0;
+}
+int ft8gpu_memcpy_d2h(ft8gpu_ctx *c, void *d, const void *s, size_t n) {
+    CHECK_COMMON(c, 0);
+    HIP_TRY(hipStreamSynchronize(c->stream));                // results of the context's own kernels are complete
+    HIP_TRY(hipMemcpy(d, s, n, hipMemcpyDeviceToHost));
+    return 0;
+}
 
 static constexpr int kHostChunk = 512;      // frames per upload chunk of a host-buffer batch
 
-#define CHECK_COMMON(c, n)                                                              \
-    if (!(c)) return fail("ctx is NULL");                                               \
-    if ((n) < 0) return fail("nframes < 0");                                            \
-    HIP_TRY(hipSetDevice((c)->device));
 
 int ft8gpu_decode_batch(ft8gpu_ctx *c, const float *iq, int nframes, struct decoder_results *decodes,
                         int32_t *n_results, int flags) {
@@ -440,7 +503,7 @@ int ft8gpu_decode_batch(ft8gpu_ctx *c, const float *iq, int nframes, struct deco
                                    (size_t)n * kMaxMessages * sizeof(struct decoder_results), hipMemcpyHostToDevice, c->stream));
             // the upload is 384 KB per frame and takes longer than the decode: pipeline it in chunks on a
             // copy stream so that the kernels of chunk k run under the upload of chunk k+1
-            const int chunk = (n > kHostChunk && c->overlap) ? kHostChunk : n;
+            const int chunk = (n > kHostChunk && !(c->debug_flags & FT8GPU_DBG_NO_OVERLAP)) ? kHostChunk : n;
             int k = 0;
             for (int g0 = 0; g0 < n; g0 += chunk, k++) {
                 const int m = (n - g0 < chunk) ? n - g0 : chunk;
@@ -461,6 +524,85 @@ int ft8gpu_decode_batch(ft8gpu_ctx *c, const float *iq, int nframes, struct deco
         }
     }
     return 0;
+}
+
+// frames resident on the context's GPU, records to host arrays (used by the multi-GPU entry)
+static int decode_dev_to_host(ft8gpu_ctx *c, const float *d_iq, int nframes, struct decoder_results *decodes, int32_t *n_results) {
+    CHECK_COMMON(c, nframes);
+    if (nframes == 0) return 0;
+    if (!d_iq || !decodes || !n_results) return fail("NULL array argument");
+    const size_t frame_floats = 2 * (size_t)kNSamples;
+    for (int f0 = 0; f0 < nframes; f0 += c->max_frames) {
+        const int n = (nframes - f0 < c->max_frames) ? nframes - f0 : c->max_frames;
+        // slots of non-CQ messages must keep the caller's bytes (rtlsdr_ft8d.c:1509-1520)
+        HIP_TRY(hipMemcpyAsync(c->d_decodes, decodes + (size_t)f0 * kMaxMessages,
+                               (size_t)n * kMaxMessages * sizeof(struct decoder_results), hipMemcpyHostToDevice, c->stream));
+        if (run_pipeline(c, d_iq + f0 * frame_floats, n, c->d_decodes, c->d_nres)) return -1;
+        HIP_TRY(hipMemcpyAsync(decodes + (size_t)f0 * kMaxMessages, c->d_decodes,
+                               (size_t)n * kMaxMessages * sizeof(struct decoder_results), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(n_results + f0, c->d_nres, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+// SURVEY.md section 8(e) for a C caller: contiguous shards, one host thread and one context per GPU; the
+// "gather" is each shard writing its records at its frame offset of the caller's host arrays.
+static int run_shards(ft8gpu_ctx *const *ctxs, int ndev, const float *const *iq_of, const int *first, const int *count,
+                      bool iq_on_device, struct decoder_results *decodes, int32_t *n_results) {
+    std::vector<int> rc((size_t)ndev, 0);
+    std::vector<std::string> why((size_t)ndev);
+    auto work = [&](int g) {
+        struct decoder_results *d = decodes + (size_t)first[g] * kMaxMessages;
+        int32_t *n = n_results + first[g];
+        rc[g] = iq_on_device ? decode_dev_to_host(ctxs[g], iq_of[g], count[g], d, n)
+                             : ft8gpu_decode_batch(ctxs[g], iq_of[g], count[g], d, n, FT8GPU_HOST_PTRS);
+        if (rc[g]) why[g] = g_err;                       // the error text is thread-local: hand it to the caller's thread
+    };
+    std::vector<std::thread> threads;
+    for (int g = 1; g < ndev; ++g) if (count[g] > 0) threads.emplace_back(work, g);
+    if (count[0] > 0) work(0);                           // shard 0 on the calling thread
+    for (auto &t : threads) t.join();
+    for (int g = 0; g < ndev; ++g)
+        if (rc[g]) return fail("shard %d of %d (frames [%d, %d)): %s", g, ndev, first[g], first[g] + count[g], why[g].c_str());
+    return 0;
+}
+
+int ft8gpu_decode_batch_multi(ft8gpu_ctx *const *ctxs, int ndev, const float *iq, int nframes,
+                              struct decoder_results *decodes, int32_t *n_results) {
+    if (!ctxs || ndev < 1) return fail("ft8gpu_decode_batch_multi: no contexts");
+    if (nframes < 0) return fail("nframes < 0");
+    if (nframes == 0) return 0;
+    if (!iq || !decodes || !n_results) return fail("NULL array argument");
+    std::vector<const float *> iq_of((size_t)ndev);
+    std::vector<int> first((size_t)ndev), count((size_t)ndev);
+    for (int g = 0; g < ndev; ++g) {
+        if (!ctxs[g]) return fail("ctxs[%d] is NULL", g);
+        for (int h = 0; h < g; ++h) if (ctxs[h] == ctxs[g]) return fail("ctxs[%d] and ctxs[%d] are the same context", h, g);
+        first[g] = (int)((long long)nframes * g / ndev);
+        count[g] = (int)((long long)nframes * (g + 1) / ndev) - first[g];
+        iq_of[g] = iq + (size_t)first[g] * 2 * kNSamples;
+    }
+    return run_shards(ctxs, ndev, iq_of.data(), first.data(), count.data(), false, decodes, n_results);
+}
+
+int ft8gpu_decode_batch_multi_dev(ft8gpu_ctx *const *ctxs, int ndev, const float *const *iq_dev, const int *nframes_dev,
+                                  struct decoder_results *decodes, int32_t *n_results) {
+    if (!ctxs || ndev < 1) return fail("ft8gpu_decode_batch_multi_dev: no contexts");
+    if (!iq_dev || !nframes_dev || !decodes || !n_results) return fail("NULL array argument");
+    std::vector<int> first((size_t)ndev), count((size_t)ndev);
+    long long total = 0;
+    for (int g = 0; g < ndev; ++g) {
+        if (!ctxs[g]) return fail("ctxs[%d] is NULL", g);
+        for (int h = 0; h < g; ++h) if (ctxs[h] == ctxs[g]) return fail("ctxs[%d] and ctxs[%d] are the same context", h, g);
+        if (nframes_dev[g] < 0) return fail("nframes_dev[%d] < 0", g);
+        if (nframes_dev[g] > 0 && !iq_dev[g]) return fail("iq_dev[%d] is NULL", g);
+        first[g] = (int)total;
+        count[g] = nframes_dev[g];
+        total += nframes_dev[g];
+        if (total > 0x7FFFFFFF) return fail("too many frames");
+    }
+    return run_shards(ctxs, ndev, iq_dev, first.data(), count.data(), true, decodes, n_results);
 }
 
 int ft8gpu_waterfall(ft8gpu_ctx *c, const float *iq, int nframes, uint8_t *mag, int flags) {
@@ -532,9 +674,9 @@ int ft8gpu_decode_candidates(ft8gpu_ctx *c, const uint8_t *mag, const ft8gpu_can
     if (nframes == 0) return 0;
     if (!mag || !cands || !counts || !status) return fail("NULL array argument");
     const int mc = c->params.max_candidates;
-    // the stage entry reports the exact ldpc_errors; FT8GPU_DECODE_PIPELINE_FORM=1 runs the form of the
+    // the stage entry reports the exact ldpc_errors; FT8GPU_DBG_PIPELINE_FORM runs the form of the
     // kernel the batch pipeline uses instead (test hook: every field but ldpc_errors must agree)
-    static const bool count_errors = [] { const char *e = getenv("FT8GPU_DECODE_PIPELINE_FORM"); return !(e && e[0] == '1'); }();
+    const bool count_errors = !(c->debug_flags & FT8GPU_DBG_PIPELINE_FORM);
     for (int f0 = 0; f0 < nframes; f0 += c->max_frames) {
         const int n = (nframes - f0 < c->max_frames) ? nframes - f0 : c->max_frames;
         const bool dev = flags & FT8GPU_DEVICE_PTRS;
@@ -548,7 +690,7 @@ int ft8gpu_decode_candidates(ft8gpu_ctx *c, const uint8_t *mag, const ft8gpu_can
             HIP_TRY(hipMemcpyAsync(c->d_counts, counts + f0, n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipMemsetAsync(c->d_status, 0, (size_t)n * mc * sizeof(ft8gpu_decode_status), c->stream));
         }
-        HIP_TRY(launch_decode(dm, dc, dn, dst, n, mc, c->params.ldpc_iters, count_errors, c->stream));
+        HIP_TRY(launch_decode(dm, dc, dn, dst, n, mc, c->params.ldpc_iters, count_errors, force_ieee(c), c->stream));
         if (!dev) {
             HIP_TRY(hipMemcpyAsync(status + (size_t)f0 * mc, dst, (size_t)n * mc * sizeof(ft8gpu_decode_status), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
@@ -699,6 +841,11 @@ int ft8gpu_pskreporter_datagrams(ft8gpu_ctx *c, const struct decoder_results *de
 
 int ft8gpu_synth_frames(ft8gpu_ctx *c, const ft8gpu_synth_signal *signals, int nframes, int nsig,
                         float noise_sigma, uint64_t seed, float *iq_dev) {
+    return ft8gpu_synth_frames_at(c, signals, nframes, nsig, noise_sigma, seed, 0, iq_dev);
+}
+
+int ft8gpu_synth_frames_at(ft8gpu_ctx *c, const ft8gpu_synth_signal *signals, int nframes, int nsig,
+                           float noise_sigma, uint64_t seed, uint64_t first_frame, float *iq_dev) {
     CHECK_COMMON(c, nframes);
     if (nframes == 0) return 0;
     if (nsig < 0 || nsig > 64) return fail("nsig_per_frame %d out of range [0, 64]", nsig);
@@ -711,7 +858,7 @@ int ft8gpu_synth_frames(ft8gpu_ctx *c, const ft8gpu_synth_signal *signals, int n
         c->sigs_cap = bytes;
     }
     if (nsig > 0) HIP_TRY(hipMemcpyAsync(c->d_sigs, signals, (size_t)nframes * nsig * sizeof(ft8gpu_synth_signal), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(launch_synth(c->d_sigs, nframes, nsig, noise_sigma, seed, iq_dev, c->stream));
+    HIP_TRY(launch_synth(c->d_sigs, nframes, nsig, noise_sigma, seed, first_frame, iq_dev, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -46,12 +46,12 @@ hipError_t launch_heap(const uint32_t *lists, const int32_t *list_counts, ft8gpu
                        int32_t *counts, int nframes, int max_candidates, hipStream_t s);
 hipError_t launch_decode(const uint8_t *mag, const ft8gpu_candidate *cands, const int32_t *counts,
                          ft8gpu_decode_status *status, int nframes, int max_candidates, int ldpc_iters,
-                         bool count_errors, hipStream_t s);
+                         bool count_errors, int force_ieee_div, hipStream_t s);
 hipError_t launch_spots(const ft8gpu_candidate *cands, const int32_t *counts,
                         const ft8gpu_decode_status *status, int nframes, int max_candidates,
                         int min_score, struct decoder_results *decodes, int32_t *n_results, hipStream_t s);
 hipError_t launch_synth(const ft8gpu_synth_signal *sig_dev, int nframes, int nsig, float noise_sigma,
-                        uint64_t seed, float *iq, hipStream_t s);
+                        uint64_t seed, uint64_t first_frame, float *iq, hipStream_t s);
 hipError_t decode_tables_init(hipStream_t s);   // uploads the LDPC edge tables used by the BP kernel
 hipError_t launch_rx(const uint8_t *raw, int ncaptures, size_t npairs, void *scratch_sums, void *scratch_base,
                      float *iq, int normalise, hipStream_t s);

@@ -20,7 +20,7 @@ constexpr int kMaxSig = 64;
 
 __global__ __launch_bounds__(1024)
 void ft8_synth_kernel(const ft8gpu_synth_signal *__restrict__ sigs, int nsig, float noise_sigma,
-                      uint64_t seed, float *__restrict__ iq) {
+                      uint64_t seed, uint64_t first_frame, float *__restrict__ iq) {
     __shared__ int s_cum[kMaxSig][80];        // prefix sums of tone numbers
     __shared__ float s_max[1024 / 64];
     __shared__ float s_scale;
@@ -38,7 +38,9 @@ void ft8_synth_kernel(const ft8gpu_synth_signal *__restrict__ sigs, int nsig, fl
     float *fQ = fI + kNSamples;
     float peak = 0.0f;
     for (int i = tid; i < kNSamples; i += blockDim.x) {
-        const uint64_t h = splitmix64(seed ^ splitmix64(((uint64_t)frame << 20) + (uint64_t)i));
+        // keyed on the GLOBAL frame index: frame g of a job gets the same noise whichever rank / shard / batch
+        // position synthesises it (first_frame = global index of this launch's frame 0)
+        const uint64_t h = splitmix64(seed ^ splitmix64(((first_frame + (uint64_t)frame) << 20) + (uint64_t)i));
         const float u1 = ((float)(uint32_t)(h >> 40) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
         const float u2 = (float)(uint32_t)((h >> 8) & 0xFFFFFFu) * (1.0f / 16777216.0f);
         const float rad = noise_sigma * sqrtf(-2.0f * logf(u1));
@@ -83,9 +85,9 @@ void ft8_synth_kernel(const ft8gpu_synth_signal *__restrict__ sigs, int nsig, fl
 }  // namespace
 
 hipError_t launch_synth(const ft8gpu_synth_signal *sig_dev, int nframes, int nsig, float noise_sigma,
-                        uint64_t seed, float *iq, hipStream_t s) {
+                        uint64_t seed, uint64_t first_frame, float *iq, hipStream_t s) {
     if (nframes < 1) return hipSuccess;
     if (nsig > kMaxSig) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ft8_synth_kernel, dim3(nframes), dim3(1024), 0, s, sig_dev, nsig, noise_sigma, seed, iq);
+    hipLaunchKernelGGL(ft8_synth_kernel, dim3(nframes), dim3(1024), 0, s, sig_dev, nsig, noise_sigma, seed, first_frame, iq);
     return hipGetLastError();
 }

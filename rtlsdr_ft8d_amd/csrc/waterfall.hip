@@ -90,7 +90,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // rtlsdr_ft8d.c:1415-1427 for one bin; qthr[k] = smallest float y with quantised value >= k
-// (qthr[0] = 0, qthr[256] = +inf).  v_log_f32 (1 ulp) puts the guess 6.0206*log2(y)+240 within
+// (qthr[0] = 0, qthr[256] = NaN: never compares true).  v_log_f32 (1 ulp) puts the guess 6.0206*log2(y)+240 within
 // 1e-2 of the reference's float expression, so the truncated guess is off by at most one step and a
 // single comparison against the two neighbouring thresholds makes it exact -- branch-free, with
 // both table reads of all eight bins of a lane in flight together.
@@ -101,6 +101,8 @@ __device__ __forceinline__ unsigned quantise(float re, float im, const float *qt
     k = k < 0 ? 0 : (k > 255 ? 255 : k);
     const float t0 = qthr[k], t1 = qthr[k + 1];
     k += (y >= t1 ? 1 : 0) - (y < t0 ? 1 : 0);
+    // (y = +inf, i.e. |X|^2 overflowed: the guess saturates to 255 and qthr[256] is NaN, so k stays 255 --
+    // the fence documented in DESIGN.md; y = NaN: the guess converts to 0 and no comparison holds, k = 0)
     return (unsigned)k;
 }
 

@@ -130,6 +130,7 @@ class SpotExchange:
             return s.view(self.frames, self.RECORD_BYTES).clone(), c.view(dtype=torch.int32).clone()
         seg = self._all[i].view(self.world, -1)
         n = self.frames * self.RECORD_BYTES
-        spots = seg[:, :n].reshape(self.world * self.frames, self.RECORD_BYTES)
-        counts = seg[:, n:].contiguous().view(dtype=torch.int32).reshape(-1)
+        # copies: the receive buffer is overwritten by the exchange of step k + 2
+        spots = seg[:, :n].reshape(self.world * self.frames, self.RECORD_BYTES).clone()
+        counts = seg[:, n:].clone(memory_format=torch.contiguous_format).view(dtype=torch.int32).reshape(-1)
         return spots, counts

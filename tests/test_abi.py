@@ -25,6 +25,7 @@ def ft8():
 def declared_functions():
     src = open(os.path.join(ROOT, "include", "ft8gpu.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"^\s*#.*$", "", src, flags=re.M)              # preprocessor lines declare nothing
     names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", src)
     return sorted(set(n for n in names if n.startswith("ft8") or n in ("initFFTW", "freeFFTW")))
 

@@ -1,0 +1,190 @@
+"""Multi-GPU path on the hardware at hand (one MI355X per box): SURVEY.md section 8(e).
+
+* the C-ABI sharded entries ft8gpu_decode_batch_multi / _multi_dev with several contexts on GPU 0
+  (one host thread per context, contiguous shards, host-side gather) against the single-context batch;
+* the synthetic workload is world-size invariant: global frame g is the same samples whoever makes it;
+* two RANKS (processes) sharing GPU 0, each decoding its shard_range of one 512-frame job with the real
+  pipeline, records exchanged with workload.SpotExchange (gloo on CPU tensors: RCCL refuses two ranks on
+  one device), gathered result byte-identical to the single-process batch.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _job(ft8, workload, dec, first, n, nsig=20, snr=(-18.0, 0.0)):
+    """frames [first, first + n) of THE job (seed SEED_BASE), synthesised in HBM by `dec`"""
+    import torch
+    _, tones = workload.message_pool()
+    sig, _ = workload.frame_signals(first, n, nsig, tones, snr_range=snr)
+    iq = torch.empty((n, 2, ft8.NSAMPLES), dtype=torch.float32, device="cuda")
+    dec.synth_frames(sig, n, nsig, 1.0, workload.SEED_BASE, iq, first_frame=first)
+    return iq
+
+
+def test_synth_is_world_size_invariant():
+    """frame g gets the same samples whether it is frame g of one call or frame g - lo of a shard"""
+    import rtlsdr_ft8d_amd as ft8
+    from rtlsdr_ft8d_amd import workload
+    total = 24
+    with ft8.Decoder(device=0, max_frames=total) as dec:
+        whole = _job(ft8, workload, dec, 0, total, nsig=5).cpu().numpy()
+        for world in (2, 3, 8):
+            parts = []
+            for r in range(world):
+                lo, hi = workload.shard_range(total, r, world)
+                parts.append(_job(ft8, workload, dec, lo, hi - lo, nsig=5).cpu().numpy())
+            assert np.concatenate(parts).tobytes() == whole.tobytes(), f"world {world}"
+        # and the noise really differs from frame to frame
+        assert not np.array_equal(whole[0], whole[1])
+
+
+def test_decode_batch_multi_contexts_on_one_gpu(oracle):
+    """ft8gpu_decode_batch_multi: ndev = 1, 2 and 3 contexts on GPU 0 (ragged shards) == one context"""
+    import rtlsdr_ft8d_amd as ft8
+    from rtlsdr_ft8d_amd import workload
+    n = 301
+    with ft8.Decoder(device=0, max_frames=n) as d0:
+        host_iq = _job(ft8, workload, d0, 100, n).cpu().numpy()
+        # slots of non-CQ messages keep the caller's bytes: start every run from the same pattern
+        pattern = np.frombuffer(np.random.default_rng(1).bytes(n * 50 * 28), np.uint8)
+        base = pattern.copy().view(ft8.RESULT_DTYPE).reshape(n, 50)
+        ref, ref_n = d0.decode_batch(host_iq, decodes=base)
+        assert int(ref_n.sum()) > 8 * n
+        with ft8.Decoder(device=0, max_frames=128) as d1, ft8.Decoder(device=0, max_frames=64) as d2:
+            for ctxs in ([d0], [d0, d1], [d1, d2, d0]):
+                got, got_n = ft8.decode_batch_multi(ctxs, host_iq, decodes=pattern.copy().view(ft8.RESULT_DTYPE).reshape(n, 50))
+                assert np.array_equal(got_n, ref_n), len(ctxs)
+                assert got.tobytes() == ref.tobytes(), len(ctxs)
+            # fewer frames than contexts: empty shards are skipped
+            got, got_n = ft8.decode_batch_multi([d0, d1, d2], host_iq[:2], decodes=pattern[:2 * 1400].copy().view(ft8.RESULT_DTYPE).reshape(2, 50))
+            assert np.array_equal(got_n, ref_n[:2]) and got.tobytes() == ref[:2].tobytes()
+            # the same context twice is refused
+            with pytest.raises(ft8.Ft8GpuError, match="same context"):
+                ft8.decode_batch_multi([d1, d1], host_iq[:4])
+    for f in (0, 150, 300):
+        rdec, rn = oracle.subsystem(host_iq[f, 0], host_iq[f, 1])
+        assert ref_n[f] == rn
+        for k in range(rn):                                     # CQ slots equal the oracle's; others keep the pattern
+            if rdec[k]["call"]:
+                assert ref[f][k].tobytes() == rdec[k].tobytes()
+
+
+def test_decode_batch_multi_device_resident_shards():
+    """ft8gpu_decode_batch_multi_dev: every shard synthesised in its context's HBM, records gathered on the host"""
+    import rtlsdr_ft8d_amd as ft8
+    from rtlsdr_ft8d_amd import workload
+    total, world = 700, 3
+    with ft8.Decoder(device=0, max_frames=total) as d0, ft8.Decoder(device=0, max_frames=100) as d1, \
+            ft8.Decoder(device=0, max_frames=400) as d2:
+        whole = _job(ft8, workload, d0, 0, total)
+        ref, ref_n = d0.decode_batch(whole.cpu().numpy())
+        ctxs = [d0, d1, d2]
+        shards, counts = [], []
+        for r in range(world):
+            lo, hi = workload.shard_range(total, r, world)
+            shards.append(_job(ft8, workload, ctxs[r], lo, hi - lo))
+            counts.append(hi - lo)
+        got, got_n = ft8.decode_batch_multi_dev(ctxs, shards, counts)
+    assert np.array_equal(got_n, ref_n) and got.tobytes() == ref.tobytes()
+
+
+def test_two_host_threads_on_one_context_serialise():
+    """the context mutex: concurrent callers of ONE context must not corrupt each other's results"""
+    import threading
+    import rtlsdr_ft8d_amd as ft8
+    from rtlsdr_ft8d_amd import workload
+    n = 96
+    with ft8.Decoder(device=0, max_frames=n) as d:
+        host = _job(ft8, workload, d, 40, 2 * n).cpu().numpy()
+        ref = [d.decode_batch(host[:n]), d.decode_batch(host[n:])]
+        out = [None, None]
+
+        def run(k):
+            for _ in range(3):
+                out[k] = d.decode_batch(host[k * n:(k + 1) * n])
+        th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+    for k in range(2):
+        assert np.array_equal(out[k][1], ref[k][1]) and out[k][0].tobytes() == ref[k][0].tobytes()
+
+
+# ---- two ranks on one GPU ------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, total, steps, q):
+    """one rank = one process: its own HIP context, its shard of the job, the real pipeline"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    import rtlsdr_ft8d_amd as ft8
+    from rtlsdr_ft8d_amd import workload
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = workload.shard_range(total, rank, world)
+    n = hi - lo
+    ok = True
+    with ft8.Decoder(device=0, max_frames=n) as dec:
+        iq = _job(ft8, workload, dec, lo, n)
+        ex = workload.SpotExchange(n, world, "cpu")                # gloo: CPU tensors
+        d_spots = torch.zeros((n, 1400), dtype=torch.uint8, device="cuda")
+        d_n = torch.zeros((n,), dtype=torch.int32, device="cuda")
+        for k in range(steps):                                     # bench.py's step structure
+            d_spots.zero_()
+            torch.cuda.synchronize()                               # the fill runs on torch's stream, the decoder on its own
+            dec.decode_batch_dev(iq, n, d_spots, d_n)
+            dec.synchronize()
+            s_buf, n_buf = ex.buffers(k)
+            s_buf.copy_(d_spots.cpu())
+            n_buf.copy_(d_n.cpu())
+            ex.launch(k)
+        g_s, g_n = ex.gathered(steps - 1)
+        ex.wait_all()
+        if rank == 0:                                              # the whole job alone, same process, same GPU
+            with ft8.Decoder(device=0, max_frames=total) as solo:
+                w_iq = _job(ft8, workload, solo, 0, total)
+                w_s = torch.zeros((total, 1400), dtype=torch.uint8, device="cuda")
+                w_n = torch.zeros((total,), dtype=torch.int32, device="cuda")
+                torch.cuda.synchronize()
+                solo.decode_batch_dev(w_iq, total, w_s, w_n)
+                solo.synchronize()
+            ok = bool(torch.equal(g_s, w_s.cpu()) and torch.equal(g_n, w_n.cpu()) and int(w_n.sum()) > 8 * total)
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok = ok and float(t.item()) == float(world)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok, lo, hi))
+
+
+def test_two_ranks_share_gpu0_and_match_the_single_process_batch():
+    import torch.multiprocessing as mp
+    world, total, steps = 2, 512, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, total, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [True, True]
+    assert (res[0][2], res[0][3], res[1][2], res[1][3]) == (0, 256, 256, 512)

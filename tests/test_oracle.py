@@ -152,6 +152,8 @@ def test_quantiser_truncation_and_clamp(oracle):
     # monotone over 30 decades
     vals = [q(float(10.0 ** e)) for e in np.linspace(-20, 10, 400)]
     assert all(b >= a for a, b in zip(vals, vals[1:]))
+    # fence for non-finite |X|^2 (the reference's int conversion is undefined there): saturate
+    assert q(float("inf")) == 255 and q(3.0e38) == 255 and q(float("nan")) == 0
 
 
 # ---- sync search ------------------------------------------------------------------------------------
