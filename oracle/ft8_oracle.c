@@ -975,11 +975,9 @@ int ft8o_decode(const uint8_t *mag, const ft8o_candidate_t *cand, ft8o_message_t
  *       no token at all (empty free text) would crash the reference at :1510; it is counted as a
  *       non-CQ message here.
  * ---------------------------------------------------------------------------------------- */
-static void spots_from_waterfall(const uint8_t *mag_power, const ft8o_params_t *p,
-                                 struct ft8o_decoder_results *decodes, int32_t *n_results) {
-    ft8o_candidate_t *candidate_list = (ft8o_candidate_t *)malloc(sizeof(ft8o_candidate_t) * (size_t)p->max_candidates);
-    int num_candidates = ft8o_find_sync(mag_power, p->max_candidates, candidate_list, p->min_score);   /* :1450 */
-
+/* the candidate loop :1452-1523 for a given candidate list (what follows ft8_find_sync at :1450) */
+void ft8o_spots_from_candidates(const uint8_t *mag_power, const ft8o_candidate_t *candidate_list, int num_candidates,
+                                const ft8o_params_t *p, struct ft8o_decoder_results *decodes, int32_t *n_results) {
     int num_decoded = 0;
     ft8o_message_t decoded[FT8O_K_MAX_MESSAGES];
     ft8o_message_t *decoded_hashtable[FT8O_K_MAX_MESSAGES];
@@ -1030,6 +1028,13 @@ static void spots_from_waterfall(const uint8_t *mag_power, const ft8o_params_t *
         }
     }
     *n_results = num_decoded;                                                                        /* :1523 */
+}
+
+static void spots_from_waterfall(const uint8_t *mag_power, const ft8o_params_t *p,
+                                 struct ft8o_decoder_results *decodes, int32_t *n_results) {
+    ft8o_candidate_t *candidate_list = (ft8o_candidate_t *)malloc(sizeof(ft8o_candidate_t) * (size_t)p->max_candidates);
+    int num_candidates = ft8o_find_sync(mag_power, p->max_candidates, candidate_list, p->min_score);   /* :1450 */
+    ft8o_spots_from_candidates(mag_power, candidate_list, num_candidates, p, decodes, n_results);
     free(candidate_list);
 }
 
@@ -1064,6 +1069,51 @@ void ft8o_subsystem_batch(const float *iq, int B, const ft8o_params_t *p,
         const float *I = iq + (size_t)f * 2 * FT8O_NSAMPLES;
         ft8o_subsystem_ex(I, I + FT8O_NSAMPLES, p, decodes + (size_t)f * FT8O_K_MAX_MESSAGES, n_results + f);
     }
+    (void)nthreads;
+}
+
+/* Batch forms of the two halves of the path, for the FFT-divergence study (tools/fft_parity.py) and the
+ * configs[1] bench leg (GPU waterfall + sync, LDPC on the host cores): the waterfall of B frames with the
+ * float32 R4DIF FFT or the float64 DFT, and everything after the waterfall (rtlsdr_ft8d.c:1438-1523). */
+void ft8o_waterfall_batch(const float *iq, int B, uint8_t *mag, int f64, int nthreads) {
+    ft8o_init();
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+#endif
+    for (int f = 0; f < B; f++) {
+        const float *I = iq + (size_t)f * 2 * FT8O_NSAMPLES;
+        if (f64) ft8o_waterfall_f64(I, I + FT8O_NSAMPLES, mag + (size_t)f * FT8O_MAG_ARRAY);
+        else ft8o_waterfall(I, I + FT8O_NSAMPLES, mag + (size_t)f * FT8O_MAG_ARRAY);
+    }
+    (void)nthreads;
+}
+
+void ft8o_subsystem_from_waterfall_batch(const uint8_t *mag, int B, const ft8o_params_t *p,
+                                         struct ft8o_decoder_results *decodes, int32_t *n_results, int nthreads) {
+    ft8o_init();
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+#endif
+    for (int f = 0; f < B; f++)
+        ft8o_subsystem_from_waterfall(mag + (size_t)f * FT8O_MAG_ARRAY, p, decodes + (size_t)f * FT8O_K_MAX_MESSAGES, n_results + f);
+    (void)nthreads;
+}
+
+/* ft8_find_sync + the candidate loop's ft8_decode calls for B frames whose candidate lists are given (the
+ * configs[1] split: the GPU hands over waterfall and candidates, the host runs LLR / BP / CRC / unpack / dedup). */
+void ft8o_decode_from_candidates_batch(const uint8_t *mag, const ft8o_candidate_t *cands, const int32_t *counts, int B,
+                                       const ft8o_params_t *p, struct ft8o_decoder_results *decodes, int32_t *n_results,
+                                       int nthreads) {
+    ft8o_init();
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+#endif
+    for (int f = 0; f < B; f++)
+        ft8o_spots_from_candidates(mag + (size_t)f * FT8O_MAG_ARRAY, cands + (size_t)f * p->max_candidates, counts[f], p,
+                                   decodes + (size_t)f * FT8O_K_MAX_MESSAGES, n_results + f);
     (void)nthreads;
 }
 
@@ -1119,6 +1169,34 @@ int ft8o_selftest_signal(float *iSamples, float *qSamples, unsigned seed) {
         }
     }
     return 1;
+}
+
+/* f-3: the modulation loop of decoderSelfTest(), rtlsdr_ft8d.c:946-955 -- plain FSK,
+ * 512 samples per symbol, the phase accumulated in double by `phi += dphi` -- generalised to S signals with
+ * their own start sample, level and frequency, summed in double and rounded to float once.  `f_tone0_hz` is
+ * the frequency of tone 0, i.e. the reference's `f0 - 3.5 * df` (its f0 = 50 Hz puts tone 0 at 28.125 Hz).
+ * No noise here: the product's generator adds its own counter-based AWGN, which has no CPU counterpart. */
+void ft8o_synth_cpfsk(const uint8_t *tones /* [nsig][79] */, const double *f_tone0_hz, const int *start_sample,
+                      const double *amplitude, int nsig, float *iSamples, float *qSamples) {
+    double *aI = (double *)calloc(FT8O_NSAMPLES, sizeof(double)), *aQ = (double *)calloc(FT8O_NSAMPLES, sizeof(double));
+    const double df = 3200.0 / 512.0, dt = 1 / 3200.0;                 /* :942-943 */
+    for (int s = 0; s < nsig; s++) {
+        double phi = 0.0;                                                /* :941 */
+        for (int i = 0; i < FT8O_NN; i++) {                              /* :946 */
+            double dphi = 2.0 * M_PI * dt * (f_tone0_hz[s] + (double)tones[s * FT8O_NN + i] * df);   /* :947 */
+            for (int j = 0; j < 512; j++) {
+                int index = start_sample[s] + 512 * i + j;               /* :949 */
+                if (index >= 0 && index < FT8O_NSAMPLES) {
+                    aI[index] += amplitude[s] * cos(phi);                /* :950 */
+                    aQ[index] += amplitude[s] * sin(phi);                /* :951 */
+                }
+                phi += dphi;                                             /* :952 */
+            }
+        }
+    }
+    for (int i = 0; i < FT8O_NSAMPLES; i++) { iSamples[i] = (float)aI[i]; qSamples[i] = (float)aQ[i]; }
+    free(aI);
+    free(aQ);
 }
 
 /* rtlsdr_ft8d.c:248-263 (decoder thread) == :763-778 (file readers) */

@@ -152,6 +152,17 @@ void ft8o_subsystem_ex(const float *iSamples, const float *qSamples, const ft8o_
 /* same, starting from a given waterfall (stage-isolated parity) */
 void ft8o_subsystem_from_waterfall(const uint8_t *mag, const ft8o_params_t *p,
                                    struct ft8o_decoder_results *decodes, int32_t *n_results);
+/* the candidate loop rtlsdr_ft8d.c:1452-1523 on a given candidate list (what follows ft8_find_sync, :1450) */
+void ft8o_spots_from_candidates(const uint8_t *mag, const ft8o_candidate_t *candidate_list, int num_candidates,
+                                const ft8o_params_t *p, struct ft8o_decoder_results *decodes, int32_t *n_results);
+/* batch forms (OpenMP over frames): waterfalls with the float32 R4DIF FFT (f64 = 0) or the float64 DFT (f64 = 1);
+ * everything after the waterfall; everything after ft8_find_sync (configs[1]: cands [B][p->max_candidates]) */
+void ft8o_waterfall_batch(const float *iq, int B, uint8_t *mag, int f64, int nthreads);
+void ft8o_subsystem_from_waterfall_batch(const uint8_t *mag, int B, const ft8o_params_t *p,
+                                         struct ft8o_decoder_results *decodes, int32_t *n_results, int nthreads);
+void ft8o_decode_from_candidates_batch(const uint8_t *mag, const ft8o_candidate_t *cands, const int32_t *counts, int B,
+                                       const ft8o_params_t *p, struct ft8o_decoder_results *decodes, int32_t *n_results,
+                                       int nthreads);
 /* B independent frames, iq planar [B][2][48000]; nthreads OpenMP threads (cpu_baseline leg) */
 void ft8o_subsystem_batch(const float *iq, int B, const ft8o_params_t *p,
                           struct ft8o_decoder_results *decodes /* [B][50] */, int32_t *n_results,
@@ -160,6 +171,9 @@ void ft8o_subsystem_batch(const float *iq, int B, const ft8o_params_t *p,
 /* rtlsdr_ft8d.c:890-955: the -t signal.  Uses libc rand() seeded with `seed` (reference: unseeded = 1). */
 int  ft8o_selftest_signal(float *iSamples, float *qSamples, unsigned seed);
 void ft8o_normalise(float *iSamples, float *qSamples, int n);   /* rtlsdr_ft8d.c:248-263 */
+/* rtlsdr_ft8d.c:946-955 generalised: nsig plain-FSK signals (phase accumulated in double), no noise */
+void ft8o_synth_cpfsk(const uint8_t *tones, const double *f_tone0_hz, const int *start_sample,
+                      const double *amplitude, int nsig, float *iSamples, float *qSamples);
 int32_t ft8o_write_raw_iq(const float *iSamples, const float *qSamples, const char *filename);
 int32_t ft8o_read_raw_iq(float *iSamples, float *qSamples, const char *filename);
 int32_t ft8o_read_c2(float *iSamples, float *qSamples, const char *filename, double *dialfreq);

@@ -201,6 +201,69 @@ def subsystem_batch(iq, params=None, nthreads=1):
     return dec, n
 
 
+def waterfall_batch(iq, f64=False, nthreads=1):
+    iq = np.ascontiguousarray(iq, np.float32)
+    B = iq.shape[0]
+    mag = np.zeros((B, MAG_ARRAY), np.uint8)
+    L = lib()
+    L.ft8o_waterfall_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    L.ft8o_waterfall_batch(iq.ctypes.data, B, mag.ctypes.data, int(f64), nthreads)
+    return mag
+
+
+def subsystem_from_waterfall_batch(mag, params=None, nthreads=1):
+    mag = np.ascontiguousarray(mag, np.uint8).reshape(-1, MAG_ARRAY)
+    B = mag.shape[0]
+    dec = np.zeros((B, MAX_MESSAGES), RESULT_DTYPE)
+    n = np.zeros(B, np.int32)
+    p = params or default_params()
+    L = lib()
+    L.ft8o_subsystem_from_waterfall_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_int]
+    L.ft8o_subsystem_from_waterfall_batch(mag.ctypes.data, B, C.byref(p), dec.ctypes.data, n.ctypes.data, nthreads)
+    return dec, n
+
+
+def decode_from_candidates_batch(mag, cands, counts, params=None, nthreads=1):
+    """everything after ft8_find_sync (rtlsdr_ft8d.c:1452-1523) for B frames: cands [B][max_candidates]"""
+    mag = np.ascontiguousarray(mag, np.uint8).reshape(-1, MAG_ARRAY)
+    B = mag.shape[0]
+    p = params or default_params()
+    cands = np.ascontiguousarray(cands)
+    counts = np.ascontiguousarray(counts, np.int32)
+    assert cands.dtype == CAND_DTYPE and cands.shape == (B, p.max_candidates)
+    dec = np.zeros((B, MAX_MESSAGES), RESULT_DTYPE)
+    n = np.zeros(B, np.int32)
+    L = lib()
+    L.ft8o_decode_from_candidates_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Params),
+                                                    C.c_void_p, C.c_void_p, C.c_int]
+    L.ft8o_decode_from_candidates_batch(mag.ctypes.data, cands.ctypes.data, counts.ctypes.data, B, C.byref(p),
+                                        dec.ctypes.data, n.ctypes.data, nthreads)
+    return dec, n
+
+
+def synth_cpfsk(tones, f_tone0_hz, start_sample, amplitude):
+    """rtlsdr_ft8d.c:946-955 generalised to S signals, no noise: (i, q) float32 [48000] each"""
+    tones = np.ascontiguousarray(tones, np.uint8).reshape(-1, 79)
+    S = tones.shape[0]
+    f = np.ascontiguousarray(f_tone0_hz, np.float64)
+    st = np.ascontiguousarray(start_sample, np.int32)
+    a = np.ascontiguousarray(amplitude, np.float64)
+    assert f.shape == st.shape == a.shape == (S,)
+    i = np.zeros(NSAMPLES, np.float32)
+    q = np.zeros(NSAMPLES, np.float32)
+    L = lib()
+    L.ft8o_synth_cpfsk.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.ft8o_synth_cpfsk(tones.ctypes.data, f.ctypes.data, st.ctypes.data, a.ctypes.data, S, i.ctypes.data, q.ctypes.data)
+    return i, q
+
+
+def normalise(i, q):
+    i = np.ascontiguousarray(i, np.float32).copy()
+    q = np.ascontiguousarray(q, np.float32).copy()
+    lib().ft8o_normalise(_fp(i), _fp(q), NSAMPLES)
+    return i, q
+
+
 def pack77(msg):
     out = np.zeros(12, np.uint8)
     rc = lib().ft8o_pack77(msg.encode(), _u8(out))

@@ -72,9 +72,14 @@ def test_decode_batch_multi_contexts_on_one_gpu(oracle):
     for f in (0, 150, 300):
         rdec, rn = oracle.subsystem(host_iq[f, 0], host_iq[f, 1])
         assert ref_n[f] == rn
-        for k in range(rn):                                     # CQ slots equal the oracle's; others keep the pattern
-            if rdec[k]["call"]:
-                assert ref[f][k].tobytes() == rdec[k].tobytes()
+        raw = ref[f].view(np.uint8).reshape(50, 28)
+        for k in range(rn):                                     # CQ slots carry the oracle's fields (snprintf leaves the bytes
+            if rdec[k]["call"]:                                 # behind the NUL alone); others keep the caller's pattern
+                cstr = lambda b: bytes(b).split(b"\0")[0]
+                assert cstr(raw[k, :13]) == rdec[k]["call"] and cstr(raw[k, 13:20]) == rdec[k]["loc"]
+                assert ref[f][k]["freq"] == rdec[k]["freq"] and ref[f][k]["snr"] == rdec[k]["snr"]
+            else:
+                assert raw[k].tobytes() == pattern[(f * 50 + k) * 28:(f * 50 + k + 1) * 28].tobytes()
 
 
 def test_decode_batch_multi_device_resident_shards():

@@ -385,6 +385,62 @@ def test_device_synth_frames_decode_and_match_oracle(oracle):
     assert found >= 0.6 * len(sent)        # most of the planted CQ calls are recovered
 
 
+def test_device_synth_waveform_matches_the_cpfsk_oracle(oracle):
+    """f-3: the on-device generator's signal part against the double-precision restatement of the
+    reference's modulation loop (rtlsdr_ft8d.c:946-955).  Noise off, so the frame is the sum of the CPFSK
+    signals, peak-normalised to 0.5 (:248-263).  Tolerance 1e-5 absolute on samples of magnitude <= 0.5:
+    the kernel evaluates sincospi of a double cycle count in float."""
+    import torch
+    import rtlsdr_ft8d_amd as ft8
+    rng = np.random.default_rng(33)
+    cases = [1, 1, 4, 20]
+    B, NS = len(cases), max(cases)
+    sig = np.zeros((B, NS), ft8.SIGNAL_DTYPE)
+    for b, ns in enumerate(cases):
+        for s in range(ns):
+            sig[b, s]["tones"] = ft8.encode(ft8.pack77_std(S.random_message(rng)))
+            sig[b, s]["f0_hz"] = rng.uniform(100, 1500)
+            sig[b, s]["t0_s"] = rng.uniform(0, 2.4) if b else 0.0      # late starts run off the end of the frame
+            sig[b, s]["amplitude"] = rng.uniform(0.1, 2.0)
+    with ft8.Decoder(device=0, max_frames=B) as d:
+        t_iq = torch.empty((B, 2, 48000), dtype=torch.float32, device="cuda")
+        d.synth_frames(sig, B, NS, 0.0, 99, t_iq)
+        iq = t_iq.cpu().numpy()
+    for b, ns in enumerate(cases):
+        start = [int(np.rint(np.float32(sig[b, s]["t0_s"]) * np.float32(3200.0))) for s in range(NS)]
+        oi, oq = oracle.synth_cpfsk(sig[b]["tones"], sig[b]["f0_hz"].astype(np.float64), start,
+                                    sig[b]["amplitude"].astype(np.float64))
+        oi, oq = oracle.normalise(oi, oq)
+        assert np.abs(iq[b, 0] - oi).max() <= 1e-5 and np.abs(iq[b, 1] - oq).max() <= 1e-5, b
+        assert abs(np.abs(iq[b]).max() - 0.5) < 1e-6
+
+
+def test_device_synth_noise_statistics():
+    """f-3: the counter-based AWGN of the generator (no CPU counterpart): mean, variance ratio, whiteness,
+    I/Q independence, Gaussian tails and frame-to-frame independence on about 10^6 samples"""
+    import torch
+    import rtlsdr_ft8d_amd as ft8
+    B = 11
+    sig = np.zeros((B, 1), ft8.SIGNAL_DTYPE)
+    with ft8.Decoder(device=0, max_frames=B) as d:
+        t_iq = torch.empty((B, 2, 48000), dtype=torch.float32, device="cuda")
+        d.synth_frames(sig, B, 0, 1.0, 4242, t_iq)
+        iq = t_iq.cpu().numpy().astype(np.float64)
+    x = iq / iq.reshape(B, -1).std(axis=1)[:, None, None]            # undo the per-frame peak normalisation
+    flat = x.reshape(-1)                                             # 1 056 000 samples
+    n = flat.size
+    assert abs(flat.mean()) < 4 / np.sqrt(n)
+    assert abs((flat ** 4).mean() - 3.0) < 0.03                      # Gaussian kurtosis
+    assert abs((np.abs(flat) > 3).mean() - 0.0026998) < 3e-4         # 3-sigma tail mass
+    for b in range(B):
+        i_, q_ = x[b, 0], x[b, 1]
+        assert abs(np.mean(i_[:-1] * i_[1:])) < 5 / np.sqrt(48000)   # lag-1 autocorrelation
+        assert abs(np.mean(i_ * q_)) < 5 / np.sqrt(48000)            # I/Q cross-correlation
+        assert 3.6 < 0.5 / iq[b].std() < 5.6                         # peak of 96 000 Gaussian samples is 4-5 sigma
+    assert abs(np.mean(x[0, 0] * x[1, 0])) < 5 / np.sqrt(48000)      # different frames are independent
+    assert abs(x[:, 0].var() / x[:, 1].var() - 1.0) < 0.01
+
+
 def test_decode_with_forced_ieee_division(oracle):
     """the BP kernel's guarded fast division falls back to the compiler's IEEE division when a
     numerator is tiny; FT8GPU_DBG_FORCE_IEEE_DIV (a per-context flag) takes that path for every
