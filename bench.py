@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- frames decoded per second by the MI355X FT8 hot path (BASELINE.json metric).
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus 1 --steps K --warmup W                       (configs[2], the default)
+  python bench.py --config 4                                          (configs[4]: oversubscribed candidate set)
+  python bench.py --config 1                                          (configs[1]: GPU waterfall + sync, LDPC on the CPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the whole decode path (waterfall FFT -> Costas sync -> LLR -> LDPC BP -> CRC ->
@@ -10,8 +12,14 @@ timed region starts.  Frames are independent, so N GPUs each take a contiguous s
 batch (weak scaling: frames per GPU fixed); the only collective is one RCCL all-gather of the
 fixed-size spot records per step, double-buffered so that it runs under the next step's kernels.
 Prints ONE JSON line on rank 0.
+
+configs[1] is the split BASELINE.json describes -- waterfall and sync search on the GPU, their results
+(94 208 B waterfall + 964 B candidate list per frame) copied to the host, LLR / BP / CRC / unpack / dedup on
+the host cores.  The host half has no product implementation (the product decodes on the GPU): it is the
+CPU oracle, i.e. this mode measures "GPU front end + reference-style CPU back end", and says so in its line.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -23,10 +31,33 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BYTES_PER_FRAME = 384000 + 1404          # IQ in + 50 spot records and the count out
+BYTES_PER_FRAME_CFG1 = 384000 + 94208 + 964   # configs[1]: IQ in + waterfall and candidate list out
 HBM_PEAK_GBPS = 8000.0                   # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_PEAK_GBPS = 6290.0              # same guide: measured copy peak (SURVEY.md 8(d) asks for both)
 FP32_VALU_PEAK = 157.3e12                # same guide: fp32 vector peak, flop/s (an FMA lane-instruction counts 2)
-FRAMES_DEFAULT = 4096                    # the PMC traffic figures in profiles/ were collected at this batch size
+
+CONFIGS = {
+    1: dict(frames=256, nsig=20, snr=(-18.0, 0.0), max_candidates=120,
+            label="configs[1]: batch of {B} synthetic frames, {S} CQ signals/frame SNR U[{lo:g},{hi:g}] dB, waterfall + sync "
+                  "(+ exact top-{C} heap) on the GPU, D2H of waterfall + candidates, LDPC/CRC/unpack/dedup on the host cores (CPU oracle)"),
+    2: dict(frames=4096, nsig=20, snr=(-18.0, 0.0), max_candidates=120,
+            label="configs[2]: batch of {B} synthetic 15 s 3200 sps IQ frames per GPU, {S} CQ signals/frame SNR U[{lo:g},{hi:g}] dB, "
+                  "full pipeline incl. HIP LDPC(174,91) BP, K_MAX_CANDIDATES={C}"),
+    4: dict(frames=1024, nsig=60, snr=(-24.0, -14.0), max_candidates=480,
+            label="configs[4]: oversubscribed candidate set, batch of {B} synthetic frames per GPU, {S} weak CQ signals/frame "
+                  "SNR U[{lo:g},{hi:g}] dB, K_MAX_CANDIDATES x4 = {C}, full pipeline incl. HIP LDPC(174,91) BP"),
+}
+
+
+def csrc_hash():
+    """identity of the kernel sources the committed PMC summaries were collected on"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rtlsdr_ft8d_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".c")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -34,15 +65,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step (configs[2])")
-    ap.add_argument("--nsig", type=int, default=20, help="FT8 signals per frame")
-    ap.add_argument("--snr", type=float, nargs=2, default=(-18.0, 0.0))
-    ap.add_argument("--max-candidates", type=int, default=120)
+    ap.add_argument("--config", type=int, choices=(1, 2, 4), default=2, help="index into BASELINE.json configs (default 2: the metric's configuration)")
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default: the config's)")
+    ap.add_argument("--nsig", type=int, default=None, help="FT8 signals per frame")
+    ap.add_argument("--snr", type=float, nargs=2, default=None)
+    ap.add_argument("--max-candidates", type=int, default=None)
     ap.add_argument("--cpu-frames", type=int, default=2048, help="frames timed on the host CPU (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-legs", action="store_true", help="skip the PCIe-inclusive end-to-end legs (host-fed decode, raw-capture replay)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the spot all-gather even with one rank (exercises the N>1 code path on one GPU)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    B = args.frames or cfg["frames"]
+    nsig = cfg["nsig"] if args.nsig is None else args.nsig
+    snr = tuple(args.snr) if args.snr else cfg["snr"]
+    maxc = args.max_candidates or cfg["max_candidates"]
+    label = cfg["label"].format(B=B, S=nsig, lo=snr[0], hi=snr[1], C=maxc)
 
     import torch
     import torch.distributed as dist
@@ -54,6 +93,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.config == 1 and world != 1:
+        raise SystemExit("--config 1 (CPU LDPC) is a single-GPU configuration")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
@@ -63,23 +104,36 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    B = args.frames
     total = B * world
     lo, hi = workload.shard_range(total, rank, world)
     assert hi - lo == B
 
-    dec = ft8.Decoder(device=local_rank, max_frames=B, min_score=10, max_candidates=args.max_candidates, ldpc_iters=20)
+    dec = ft8.Decoder(device=local_rank, max_frames=B, min_score=10, max_candidates=maxc, ldpc_iters=20)
     # one explicit torch stream carries both the decoder kernels and the RCCL gather, so that the
     # collective is ordered after the kernels that produce the spot records
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     dec.set_stream(stream.cuda_stream)
 
-    # ---- synthetic frames, generated in HBM (not timed) ----------------------------------------
+    # ---- synthetic frames, generated in HBM (not timed); global frame g is the same samples for any world size
     _, pool_tones = workload.message_pool()
-    sig, _ = workload.frame_signals(lo, B, args.nsig, pool_tones, snr_range=tuple(args.snr))
+    sig, _ = workload.frame_signals(lo, B, nsig, pool_tones, snr_range=snr)
     iq = torch.empty((B, 2, ft8.NSAMPLES), dtype=torch.float32, device=dev)
-    dec.synth_frames(sig, B, args.nsig, 1.0, workload.SEED_BASE, iq, first_frame=lo)
+    dec.synth_frames(sig, B, nsig, 1.0, workload.SEED_BASE, iq, first_frame=lo)
+
+    out = {
+        "metric": "15 s FT8 frames decoded/s", "value": None, "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": label, "frames_per_gpu": B, "global_frames": total, "parallelism": f"frame-sharded x{world}"},
+    }
+
+    if args.config == 1:
+        run_config1(args, out, dec, iq, B, maxc, stream, dev)
+        dec.close()
+        print(json.dumps(out), flush=True)
+        return
+
     # spot records: two buffers per rank; the exchange of step k (one asynchronous RCCL all-gather of
     # records + counts) runs under the kernels of step k + 1 and is drained inside the timed region
     exch = workload.SpotExchange(B, world, dev, collective=use_dist)
@@ -118,43 +172,25 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
-    frames_total = total * args.steps
-    value = frames_total / elapsed
-    ms_per_step = 1e3 * elapsed / args.steps
-
-    n_host = nres.cpu().numpy()
-    out = {
-        "metric": "15 s FT8 frames decoded/s",
-        "value": round(value, 1),
-        "unit": "frames/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic",
-        "config": {
-            "workload": f"configs[2]: batch of {B} synthetic 15 s 3200 sps IQ frames per GPU, {args.nsig} CQ signals/frame "
-                        f"SNR U[{args.snr[0]:g},{args.snr[1]:g}] dB, full pipeline incl. HIP LDPC(174,91) BP, "
-                        f"K_MAX_CANDIDATES={args.max_candidates}",
-            "frames_per_gpu": B, "global_frames": total, "parallelism": f"frame-sharded x{world}",
-            "decoded_messages_per_frame": round(float(n_host.mean()), 2),
-        },
-    }
+    out["value"] = round(total * args.steps / elapsed, 1)
+    out["ms_per_step"] = round(1e3 * elapsed / args.steps, 3)
+    out["config"]["decoded_messages_per_frame"] = round(float(nres.cpu().numpy().mean()), 2)
     if rank == 0:
         launches = int(stage_avg.pop("launches_per_stage", 1))
         kernels = {k: v for k, v in stage_avg.items() if k != "total_ms"}
         dom = max(kernels, key=kernels.get)
         dom_ms = kernels[dom]
+        name = dom.replace("_ms", "")
         achieved = BYTES_PER_FRAME * B / (dom_ms * 1e-3) / 1e9
+        pmc = pmc_figures(name, B, launches, dom_ms / launches) if args.config == 2 else {"pmc_from": None}
         out["roofline"] = {
-            "bound": "hbm", "kernel": dom.replace("_ms", ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": _pmc_traffic(dom.replace("_ms", ""), B, launches),
-            "valu_busy_frac_pmc": _pmc_valu_busy(dom.replace("_ms", "")),
-            "valu_frac_of_fp32_peak_pmc": _pmc_valu_fraction(dom.replace("_ms", ""), B, launches, dom_ms / launches),
+            # the contract's figure: algorithmic bytes of the launch / the dominant kernel's duration, against HBM
+            "bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": pmc.get("traffic"),
+            # what actually binds this kernel (the path is not HBM-bound)
+            "binding_resource": "valu-issue" if name == "decode" else None,
+            "valu_busy_frac_pmc": pmc.get("valu_busy"), "valu_frac_of_fp32_peak_pmc": pmc.get("valu_frac"),
+            "kernel_hbm_GBps_from_traffic": pmc.get("kernel_hbm_GBps"), "pmc_from": pmc.get("pmc_from"),
             "frac_of_measured_copy_peak": round(achieved / HBM_COPY_PEAK_GBPS, 5),
             "kernel_ms": round(dom_ms, 4), "kernel_launches_per_step": launches,
             "kernel_ms_per_launch": round(dom_ms / launches, 4), "algorithmic_bytes_per_launch": BYTES_PER_FRAME * B // launches,
@@ -162,7 +198,9 @@ def main():
             "pipeline_achieved_GBps": round(BYTES_PER_FRAME * B / (stage_avg["total_ms"] * 1e-3) / 1e9, 2),
         }
         if world == 1 and not args.no_cpu_baseline and args.cpu_frames > 0:
-            out["cpu_baseline"] = cpu_baseline(iq, spots, nres, min(args.cpu_frames, B), args.max_candidates)
+            out["cpu_baseline"] = cpu_baseline(iq, spots, nres, min(args.cpu_frames, B), maxc)
+        if world == 1 and not args.no_host_legs:
+            out["end_to_end"] = host_legs(dec, iq, spots, nres, B)
     dec.close()
     if use_dist:
         dist.barrier()
@@ -178,46 +216,97 @@ def main():
         print(json.dumps(out), flush=True)          # the one JSON line, after any library banners
 
 
-def _pmc_valu_busy(kernel):
-    """fraction of SIMD cycles with a VALU instruction in flight for the dominant kernel, from the committed
-    PMC summary (the path is VALU-bound, so this is the roof that actually binds)"""
+def run_config1(args, out, dec, iq, B, maxc, stream, dev):
+    """configs[1]: waterfall + sync (+ exact heap) on the GPU, results to the host, LDPC on the host cores"""
+    import torch
+    import rtlsdr_ft8d_amd as ft8
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    oracle_lib.lib()
+    cores = usable_cores()
+    p = oracle_lib.default_params(10, maxc, 20)
+    mag = torch.empty((B, ft8.MAG_ARRAY), dtype=torch.uint8, device=dev)
+    cands = torch.empty((B, maxc, 8), dtype=torch.uint8, device=dev)
+    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    h_mag = torch.empty((B, ft8.MAG_ARRAY), dtype=torch.uint8).pin_memory()
+    h_cands = torch.empty((B, maxc, 8), dtype=torch.uint8).pin_memory()
+    h_counts = torch.empty((B,), dtype=torch.int32).pin_memory()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    acc = {"waterfall_ms": 0.0, "sync_heap_ms": 0.0, "d2h_ms": 0.0, "cpu_ldpc_ms": 0.0}
+    res = {}
+
+    def step(timed):
+        ev[0].record(stream)
+        dec.waterfall_dev(iq, B, mag)
+        ev[1].record(stream)
+        dec.find_sync_dev(mag, B, cands, counts)
+        ev[2].record(stream)
+        h_mag.copy_(mag, non_blocking=True)
+        h_cands.copy_(cands, non_blocking=True)
+        h_counts.copy_(counts, non_blocking=True)
+        ev[3].record(stream)
+        stream.synchronize()
+        t = time.perf_counter()
+        res["dec"], res["n"] = oracle_lib.decode_from_candidates_batch(
+            h_mag.numpy(), h_cands.numpy().view(oracle_lib.CAND_DTYPE).reshape(B, maxc), h_counts.numpy(), p, cores)
+        if timed:
+            acc["cpu_ldpc_ms"] += 1e3 * (time.perf_counter() - t)
+            acc["waterfall_ms"] += ev[0].elapsed_time(ev[1])
+            acc["sync_heap_ms"] += ev[1].elapsed_time(ev[2])
+            acc["d2h_ms"] += ev[2].elapsed_time(ev[3])
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    stage = {k: v / args.steps for k, v in acc.items()}
+    out["value"] = round(B * args.steps / elapsed, 1)
+    out["ms_per_step"] = round(1e3 * elapsed / args.steps, 3)
+    out["config"]["decoded_messages_per_frame"] = round(float(res["n"].mean()), 2)
+    out["config"]["host_cores_for_ldpc"] = cores
+    gpu_ms = stage["waterfall_ms"] + stage["sync_heap_ms"] + stage["d2h_ms"]
+    dom_ms = stage["waterfall_ms"]
+    achieved = BYTES_PER_FRAME_CFG1 * B / (dom_ms * 1e-3) / 1e9
+    out["roofline"] = {"bound": "hbm", "kernel": "waterfall", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                       "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None, "kernel_ms": round(dom_ms, 4),
+                       "algorithmic_bytes_per_launch": BYTES_PER_FRAME_CFG1 * B,
+                       "stage_ms": {k: round(v, 4) for k, v in stage.items()},
+                       "gpu_part_frames_per_s": round(B / (gpu_ms * 1e-3), 1),
+                       "note": "the step time is the host LDPC; the GPU part (waterfall + sync + heap + D2H) alone would run at gpu_part_frames_per_s"}
+    # the same frames through the all-GPU path must give the same records
+    gd, gn = dec.decode_batch(iq.cpu().numpy())
+    same = sum(int(gn[k] == res["n"][k] and gd[k].tobytes() == res["dec"][k].tobytes()) for k in range(B))
+    out["cpu_baseline"] = {"value": round(B / (stage["cpu_ldpc_ms"] * 1e-3), 2), "unit": "frames/s", "cores": cores, "kind": "port",
+                           "sample": f"the LDPC half of every step: oracle ft8o_decode_from_candidates_batch on {B} frames, OpenMP {cores} threads",
+                           "identical_to_all_gpu_path": f"{same}/{B}"}
+
+
+def pmc_figures(kernel, frames, launches, ms_per_launch):
+    """PMC-derived figures of the dominant kernel from the committed rocprofv3 summaries (profiles/pmc_traffic.json,
+    profiles/pmc_counters.json: FETCH_SIZE / WRITE_SIZE / SQ passes over this very command, tools/gpu_round.sh).
+    They describe the kernel sources they were collected on: the summary carries a hash of csrc/ and the figures
+    are reported only while it matches the tree this bench runs from (and the launch size); otherwise null."""
+    none = {"traffic": None, "valu_busy": None, "valu_frac": None, "kernel_hbm_GBps": None, "pmc_from": None}
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f).get(kernel, {}).get("valu_busy_frac")
+            t = json.load(f)
+        with open(os.path.join(ROOT, "profiles", "pmc_counters.json")) as f:
+            c = json.load(f)
     except (OSError, ValueError):
-        return None
-
-
-def _pmc_valu_fraction(kernel, frames, launches, ms_per_launch):
-    """SURVEY.md 8(d) "valu_fraction": VALU lane-operations per second of the dominant kernel over the fp32
-    vector peak.  SQ_INSTS_VALU (wave instructions per launch, committed PMC pass at this batch size) x 64
-    lanes / the live launch duration; one operation per lane-instruction (a packed or fused instruction
-    carries two, so this is a lower bound), against a peak that counts two per lane and clock."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            if json.load(f).get(kernel, {}).get("frames_per_launch") != frames // launches:
-                return None
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_counters_final.json")) as f:
-            insts = json.load(f)[kernel]["SQ_INSTS_VALU"]
-        return round(insts * 64 / (ms_per_launch * 1e-3) / FP32_VALU_PEAK, 4)
-    except (OSError, ValueError, KeyError):
-        return None
-
-
-def _pmc_traffic(kernel, frames, launches):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
-    (profiles/pmc_traffic.json, FETCH_SIZE / WRITE_SIZE passes over this very command; counters were
-    collected with one launch per stage and are scaled to the frames one launch covers now); None
-    until it has been collected for this kernel and batch size."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        with open(p) as f:
-            e = json.load(f).get(kernel, {})
-        if not e or e.get("frames_per_launch") != frames // launches:
-            return None
-        return int(e["hbm_bytes_per_launch"])
-    except (OSError, ValueError):
-        return None
+        return none
+    e = t.get(kernel, {})
+    if not e or e.get("frames_per_launch") != frames // launches or t.get("csrc_sha") != csrc_hash():
+        return none
+    traffic = int(e["hbm_bytes_per_launch"])
+    insts = c.get(kernel, {}).get("SQ_INSTS_VALU")
+    return {"traffic": traffic, "valu_busy": e.get("valu_busy_frac"),
+            "valu_frac": round(insts * 64 / (ms_per_launch * 1e-3) / FP32_VALU_PEAK, 4) if insts else None,
+            "kernel_hbm_GBps": round(traffic / (ms_per_launch * 1e-3) / 1e9, 1),
+            "pmc_from": f"profiles/pmc_traffic.json + pmc_counters.json @ csrc {t.get('csrc_sha')}"}
 
 
 def usable_cores():
@@ -264,10 +353,41 @@ def cpu_baseline(iq, spots, nres, m, max_candidates):
     g_n = nres[:m].cpu().numpy()
     same = sum(int(g_n[k] == rn[k] and g_dec[k].tobytes() == rdec[k].tobytes()) for k in range(m))
     return {"value": round(m / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"first {m} frames of the bench batch through oracle ft8o_subsystem_batch (gcc -O2, own radix-4 FFT, "
-                      f"OpenMP {cores} threads), {dt:.2f} s wall",
+            "sample": f"first {m} frames of the bench batch through oracle ft8o_subsystem_batch (gcc -O3 -ffp-contract=off, own radix-4 FFT "
+                      f"-- fftw3f is not installed on the box --, OpenMP {cores} threads), {dt:.2f} s wall",
             "single_core_frames_per_s": round(m1 / dt1, 2), "os_cpu_count": os.cpu_count(),
             "gpu_vs_oracle_identical_frames": f"{same}/{m}"}
+
+
+def host_legs(dec, iq, spots, nres, B):
+    """The PCIe-inclusive rates a replay user sees, beside the HBM-resident `value` (never instead of it):
+    host_fed: ft8gpu_decode_batch on frames in (pinned) host memory, 384 KB/frame uploaded in 512-frame chunks
+              on a copy stream under the kernels of the previous chunk, records copied back;
+    rx_host_fed: ft8gpu_rx_decimate on raw 2.4 Msps u8 captures in host memory (72 MB per 15 s capture) followed
+              by the decode of the frames it produces."""
+    import torch
+    out = {}
+    m = min(B, 2048)
+    h = iq[:m].cpu().pin_memory().numpy()
+    dec.decode_batch(h[:min(m, 512)])                                    # warm-up (staging allocation)
+    t0 = time.perf_counter()
+    d, n = dec.decode_batch(h)
+    dt = time.perf_counter() - t0
+    same = bool(np.array_equal(n, nres[:m].cpu().numpy())) and d.tobytes() == spots[:m].cpu().numpy().tobytes()
+    out["host_fed_frames_per_s"] = round(m / dt, 1)
+    out["host_fed"] = {"frames": m, "ms": round(1e3 * dt, 2), "upload_GBps": round(m * 384000 / dt / 1e9, 1), "records_identical_to_hbm_resident_run": same}
+    ncap, npairs = 4, 36_000_000                                         # 15 s at 2.4 Msps
+    raw = torch.randint(0, 256, (ncap, 2 * npairs), dtype=torch.uint8, generator=torch.Generator().manual_seed(3)).pin_memory().numpy()
+    dec.rx_decimate(raw[:1])                                             # warm-up
+    t0 = time.perf_counter()
+    frames = dec.rx_decimate(raw)
+    t1 = time.perf_counter()
+    dec.decode_batch(frames)
+    t2 = time.perf_counter()
+    out["rx_host_fed_captures_per_s"] = round(ncap / (t2 - t0), 2)
+    out["rx_host_fed"] = {"captures": ncap, "raw_bytes_per_capture": 2 * npairs, "decimate_ms": round(1e3 * (t1 - t0), 2),
+                          "decode_ms": round(1e3 * (t2 - t1), 2), "upload_GBps": round(ncap * 2 * npairs / (t1 - t0) / 1e9, 1)}
+    return out
 
 
 if __name__ == "__main__":

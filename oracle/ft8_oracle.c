@@ -862,11 +862,11 @@ int ft8o_pack77(const char *msg, uint8_t *b77) {
     b77[0] = (uint8_t)(n28a >> 21);
     b77[1] = (uint8_t)(n28a >> 13);
     b77[2] = (uint8_t)(n28a >> 5);
-    b77[3] = (uint8_t)((uint8_t)(n28a << 3) | (uint8_t)(n28b >> 26));
+    b77[3] = (uint8_t)((uint8_t)((uint32_t)n28a << 3) | (uint8_t)(n28b >> 26));
     b77[4] = (uint8_t)(n28b >> 18);
     b77[5] = (uint8_t)(n28b >> 10);
     b77[6] = (uint8_t)(n28b >> 2);
-    b77[7] = (uint8_t)((uint8_t)(n28b << 6) | (uint8_t)(igrid4 >> 10));
+    b77[7] = (uint8_t)((uint8_t)((uint32_t)n28b << 6) | (uint8_t)(igrid4 >> 10));
     b77[8] = (uint8_t)(igrid4 >> 2);
     b77[9] = (uint8_t)((uint8_t)(igrid4 << 6) | (uint8_t)(i3 << 3));
     b77[10] = 0;

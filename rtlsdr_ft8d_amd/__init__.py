@@ -289,6 +289,10 @@ class Decoder:
         _check(self.lib.ft8gpu_decode_batch(self.h, _ptr(iq_dev), nframes, _ptr(decodes_dev), _ptr(n_results_dev),
                                             DEVICE_PTRS))
 
+    def find_sync_dev(self, mag_dev, nframes, cands_dev, counts_dev):
+        """cands_dev: [nframes][max_candidates] 8-byte records, counts_dev: [nframes] int32 (all in HBM)"""
+        _check(self.lib.ft8gpu_find_sync(self.h, _ptr(mag_dev), nframes, _ptr(cands_dev), _ptr(counts_dev), DEVICE_PTRS))
+
     def waterfall_dev(self, iq_dev, nframes, mag_dev):
         _check(self.lib.ft8gpu_waterfall(self.h, _ptr(iq_dev), nframes, _ptr(mag_dev), DEVICE_PTRS))
 

@@ -53,7 +53,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    path = os.path.join(ORACLE_DIR, "libft8oracle.so")
+    path = os.environ.get("FT8O_LIB") or os.path.join(ORACLE_DIR, "libft8oracle.so")      # FT8O_LIB: the sanitizer build
     if not os.path.exists(path):
         build()
     L = C.CDLL(path)

@@ -12,7 +12,23 @@ waterfall kernel requests 23 x 2816 x 8 B x 4096 frames = 2.12 GB per launch and
 import argparse
 import collections
 import csv
+import hashlib
 import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def csrc_hash():
+    """identity of the kernel sources the counters were collected on (bench.py recomputes it and reports the
+    PMC figures only while it matches)"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rtlsdr_ft8d_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".c")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 KERNELS = ("ft8_decode_kernel", "ft8_waterfall_kernel", "ft8_sync_kernel", "ft8_heap_kernel", "ft8_spots_kernel",
            "ft8_synth_kernel", "ft8_rx_block_kernel")
@@ -48,7 +64,8 @@ def main():
         out[k]["dispatches"] = max(len(v) for v in d.values())
     print(json.dumps(out, indent=1))
     if args.traffic:
-        t = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over "
+        t = {"csrc_sha": csrc_hash(),
+             "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over "
                        "`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline`, mean per dispatch; tools/gpu_round.sh + tools/pmc_summary.py"}
         for k, v in out.items():
             if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v or k == "synth":
