@@ -22,6 +22,7 @@ def main():
         sig, picks = workload.frame_signals(5_000_000 + (snr + 30) * B, B, 1, tones, snr_range=(snr, snr))
         dec.synth_frames(sig, B, 1, 1.0, 4242 + snr, iq)
         spots.zero_()
+        torch.cuda.synchronize()                     # the fill runs on torch's stream, the decoder on its own
         dec.decode_batch_dev(iq, B, spots, nres)
         dec.synchronize()
         g = spots.cpu().numpy().view(ft8.RESULT_DTYPE).reshape(B, 50)

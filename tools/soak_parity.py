@@ -37,6 +37,7 @@ def main():
         sig, _ = workload.frame_signals(1_000_000 + b * B, B, nsig, tones, snr_range=(lo_snr, hi_snr))
         dec.synth_frames(sig, B, nsig, 1.0, 777 + b, iq)
         spots.zero_()
+        torch.cuda.synchronize()                     # the fill runs on torch's stream, the decoder on its own
         dec.decode_batch_dev(iq, B, spots, nres)
         dec.synchronize()
         g = spots.cpu().numpy().view(ft8.RESULT_DTYPE).reshape(B, 50)
