@@ -421,7 +421,7 @@ def test_device_synth_noise_statistics():
     import torch
     import rtlsdr_ft8d_amd as ft8
     B = 11
-    sig = np.zeros((B, 1), ft8.SIGNAL_DTYPE)
+    sig = np.zeros((B, 0), ft8.SIGNAL_DTYPE)                          # no signals: noise only
     with ft8.Decoder(device=0, max_frames=B) as d:
         t_iq = torch.empty((B, 2, 48000), dtype=torch.float32, device="cuda")
         d.synth_frames(sig, B, 0, 1.0, 4242, t_iq)
