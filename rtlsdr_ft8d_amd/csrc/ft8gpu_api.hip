@@ -96,11 +96,11 @@ struct ft8gpu_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool timing = false;
-    static constexpr int kTimingSlots = 32, kEvPerSlot = 14;
+    static constexpr int kTimingSlots = 32, kEvPerSlot = 16, kSideEv0 = 10;
     hipEvent_t ev[kTimingSlots][kEvPerSlot]{};   // ring of per-run stage events (no host sync while timing):
-                                                 // 0..7 on the main stream, 8..13 on the side stream
+                                                 // 0..9 on the main stream, 10..15 on the side stream
     long runs = 0;                         // pipeline runs recorded since timing was enabled
-    bool slot_overlapped[kTimingSlots]{};  // which form of the pipeline a slot recorded
+    int slot_form[kTimingSlots]{};         // which form of the pipeline a slot recorded: 0 plain, 1 two halves, 2 two halves on two streams
     hipStream_t side = nullptr;            // carries the serial kernels (heap, spots) of one half-batch
                                            // while the main stream works on the other half
     hipEvent_t dep[6]{};                   // cross-stream dependencies (no timing)
@@ -170,14 +170,15 @@ struct StageTimer {
     ft8gpu_ctx *c;
     explicit StageTimer(ft8gpu_ctx *ctx) : c(ctx) {}
     void mark(int i) { if (c->timing) (void)hipEventRecord(c->ev[c->runs % ft8gpu_ctx::kTimingSlots][i], c->stream); }
-    void mark_side(int i) { if (c->timing) (void)hipEventRecord(c->ev[c->runs % ft8gpu_ctx::kTimingSlots][8 + i], c->side); }
-    void done(bool overlapped) {
+    void mark_side(int i) { if (c->timing) (void)hipEventRecord(c->ev[c->runs % ft8gpu_ctx::kTimingSlots][ft8gpu_ctx::kSideEv0 + i], c->side); }
+    void done(int form) {
         if (!c->timing) return;
-        c->slot_overlapped[c->runs % ft8gpu_ctx::kTimingSlots] = overlapped;
+        c->slot_form[c->runs % ft8gpu_ctx::kTimingSlots] = form;
         c->runs++;
     }
 };
 
+inline int sync_old(const ft8gpu_ctx *c) { return (c->debug_flags & FT8GPU_DBG_SYNC_OLD) ? 1 : 0; }
 inline int force_ieee(const ft8gpu_ctx *c) { return (c->debug_flags & FT8GPU_DBG_FORCE_IEEE_DIV) ? 1 : 0; }
 
 float elapsed(hipEvent_t a, hipEvent_t b) {
@@ -189,30 +190,41 @@ float elapsed(hipEvent_t a, hipEvent_t b) {
 // Large batches: the two serial kernels (exact heap replay, spot collection) keep only one lane per
 // frame busy, so they run on a side stream for one half of the batch while the main stream runs the
 // throughput kernels of the other half:
-//   main: waterfall(all) sync(H0) sync(H1) ...wait heap(H0)... decode(H0) ...wait heap(H1)... decode(H1) spots(H1)
-//   side:                 heap(H0)          heap(H1)                       spots(H0)
+//   main: waterfall(H0) sync(H0) waterfall(H1) sync(H1) ..wait heap(H0).. decode(H0) ..wait heap(H1).. decode(H1) spots(H1)
+//   side:                        heap(H0)                                    heap(H1)              spots(H0)
+// heap(H0) hides under the front end of the second half, heap(H1) and spots(H0) under the LDPC kernels.
+// With FT8GPU_DBG_DECODE_TWO_STREAMS the second half's LDPC kernel and spots follow heap(H1) on the side
+// stream instead, so they fill the CUs the first half's kernel leaves idle while its last blocks drain.
 int run_pipeline_overlapped(ft8gpu_ctx *c, const float *d_iq, int n, struct decoder_results *d_dec, int32_t *d_nres) {
     StageTimer t(c);
     const ft8gpu_params &p = c->params;
     const int mc = p.max_candidates;
     const int n0 = n / 2, n1 = n - n0;
     const size_t lo = (size_t)n0;                                   // frame offset of the second half
+    const float *iq1 = d_iq + lo * 2 * (size_t)kNSamples;
     uint8_t *mag1 = c->d_mag + lo * kMagArray;
     uint32_t *lists1 = c->d_lists + lo * kSublistsPerFrame * kSublistCap;
     int32_t *lc1 = c->d_list_counts + lo * kSublistsPerFrame;
     ft8gpu_candidate *cands1 = c->d_cands + lo * mc;
     int32_t *counts1 = c->d_counts + lo;
     ft8gpu_decode_status *st1 = c->d_status + lo * mc;
-    hipEvent_t *E = c->dep;          // 0: sync(H0) done  1: sync(H1) done  2: heap(H0)  3: heap(H1)  4: decode(H0)  5: spots(H0)
+    const int wf_old = (c->debug_flags & FT8GPU_DBG_WF_OLD) ? 1 : 0;
+    const bool two_streams = (c->debug_flags & FT8GPU_DBG_DECODE_TWO_STREAMS) != 0;
+    hipEvent_t *E = c->dep;          // 0: sync(H0) done  1: sync(H1) done  2: heap(H0)  3: heap(H1)  4: decode(H0)  5: side stream done
 
+    // main stream events: 0 wf(H0) 1 sync(H0) 2 wf(H1) 3 sync(H1) 4 | 5 decode(H0) 6 [decode(H1) 7 spots(H1) 8] | 9 end
+    // side stream events: 0 heap(H0) 1 | 2 heap(H1) 3 | 4 spots(H0) or decode(H1)+spots(H1) 5
     t.mark(0);
-    HIP_TRY(launch_waterfall(d_iq, c->d_mag, c->d_tab, n, c->num_cus, c->stream));
+    HIP_TRY(launch_waterfall(d_iq, c->d_mag, c->d_tab, n0, c->num_cus, wf_old, c->stream));
     t.mark(1);
-    HIP_TRY(launch_sync(c->d_mag, c->d_lists, c->d_list_counts, nullptr, n0, p.min_score, c->stream));
+    HIP_TRY(launch_sync(c->d_mag, c->d_lists, c->d_list_counts, nullptr, n0, p.min_score, sync_old(c), c->stream));
     HIP_TRY(hipEventRecord(E[0], c->stream));
-    HIP_TRY(launch_sync(mag1, lists1, lc1, nullptr, n1, p.min_score, c->stream));
-    HIP_TRY(hipEventRecord(E[1], c->stream));
     t.mark(2);
+    HIP_TRY(launch_waterfall(iq1, mag1, c->d_tab, n1, c->num_cus, wf_old, c->stream));
+    t.mark(3);
+    HIP_TRY(launch_sync(mag1, lists1, lc1, nullptr, n1, p.min_score, sync_old(c), c->stream));
+    HIP_TRY(hipEventRecord(E[1], c->stream));
+    t.mark(4);
     // side stream: heap(H0), heap(H1)
     HIP_TRY(hipStreamWaitEvent(c->side, E[0], 0));
     t.mark_side(0);
@@ -224,26 +236,37 @@ int run_pipeline_overlapped(ft8gpu_ctx *c, const float *d_iq, int n, struct deco
     HIP_TRY(launch_heap(lists1, lc1, cands1, counts1, n1, mc, c->side));
     t.mark_side(3);
     HIP_TRY(hipEventRecord(E[3], c->side));
-    // main stream: decode(H0), decode(H1), spots(H1)
+    // main stream: decode(H0)
     HIP_TRY(hipStreamWaitEvent(c->stream, E[2], 0));
-    t.mark(3);
-    HIP_TRY(launch_decode(c->d_mag, c->d_cands, c->d_counts, c->d_status, n0, mc, p.ldpc_iters, false, force_ieee(c), c->stream));
-    t.mark(4);
-    HIP_TRY(hipEventRecord(E[4], c->stream));
-    HIP_TRY(hipStreamWaitEvent(c->stream, E[3], 0));
-    HIP_TRY(launch_decode(mag1, cands1, counts1, st1, n1, mc, p.ldpc_iters, false, force_ieee(c), c->stream));
     t.mark(5);
-    // side stream: spots(H0) while decode(H1) runs
-    HIP_TRY(hipStreamWaitEvent(c->side, E[4], 0));
-    t.mark_side(4);
-    HIP_TRY(launch_spots(c->d_cands, c->d_counts, c->d_status, n0, mc, p.min_score, d_dec, d_nres, c->side));
-    t.mark_side(5);
-    HIP_TRY(hipEventRecord(E[5], c->side));
-    HIP_TRY(launch_spots(cands1, counts1, st1, n1, mc, p.min_score, d_dec + lo * kMaxMessages, d_nres + lo, c->stream));
+    HIP_TRY(launch_decode(c->d_mag, c->d_cands, c->d_counts, c->d_status, n0, mc, p.ldpc_iters, false, force_ieee(c), c->stream));
     t.mark(6);
+    if (two_streams) {
+        t.mark_side(4);
+        HIP_TRY(launch_decode(mag1, cands1, counts1, st1, n1, mc, p.ldpc_iters, false, force_ieee(c), c->side));
+        HIP_TRY(launch_spots(cands1, counts1, st1, n1, mc, p.min_score, d_dec + lo * kMaxMessages, d_nres + lo, c->side));
+        t.mark_side(5);
+        HIP_TRY(hipEventRecord(E[5], c->side));
+        t.mark(7);
+        HIP_TRY(launch_spots(c->d_cands, c->d_counts, c->d_status, n0, mc, p.min_score, d_dec, d_nres, c->stream));
+        t.mark(8);
+    } else {
+        HIP_TRY(hipEventRecord(E[4], c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, E[3], 0));
+        HIP_TRY(launch_decode(mag1, cands1, counts1, st1, n1, mc, p.ldpc_iters, false, force_ieee(c), c->stream));
+        t.mark(7);
+        // side stream: spots(H0) while decode(H1) runs
+        HIP_TRY(hipStreamWaitEvent(c->side, E[4], 0));
+        t.mark_side(4);
+        HIP_TRY(launch_spots(c->d_cands, c->d_counts, c->d_status, n0, mc, p.min_score, d_dec, d_nres, c->side));
+        t.mark_side(5);
+        HIP_TRY(hipEventRecord(E[5], c->side));
+        HIP_TRY(launch_spots(cands1, counts1, st1, n1, mc, p.min_score, d_dec + lo * kMaxMessages, d_nres + lo, c->stream));
+        t.mark(8);
+    }
     HIP_TRY(hipStreamWaitEvent(c->stream, E[5], 0));
-    t.mark(7);
-    t.done(true);
+    t.mark(9);
+    t.done(two_streams ? 2 : 1);
     return 0;
 }
 
@@ -253,9 +276,9 @@ int run_pipeline(ft8gpu_ctx *c, const float *d_iq, int n, struct decoder_results
     StageTimer t(c);
     const ft8gpu_params &p = c->params;
     t.mark(0);
-    HIP_TRY(launch_waterfall(d_iq, c->d_mag, c->d_tab, n, c->num_cus, c->stream));
+    HIP_TRY(launch_waterfall(d_iq, c->d_mag, c->d_tab, n, c->num_cus, (c->debug_flags & FT8GPU_DBG_WF_OLD) ? 1 : 0, c->stream));
     t.mark(1);
-    HIP_TRY(launch_sync(c->d_mag, c->d_lists, c->d_list_counts, nullptr, n, p.min_score, c->stream));
+    HIP_TRY(launch_sync(c->d_mag, c->d_lists, c->d_list_counts, nullptr, n, p.min_score, sync_old(c), c->stream));
     t.mark(2);
     HIP_TRY(launch_heap(c->d_lists, c->d_list_counts, c->d_cands, c->d_counts, n, p.max_candidates, c->stream));
     t.mark(3);
@@ -263,7 +286,7 @@ int run_pipeline(ft8gpu_ctx *c, const float *d_iq, int n, struct decoder_results
     t.mark(4);
     HIP_TRY(launch_spots(c->d_cands, c->d_counts, c->d_status, n, p.max_candidates, p.min_score, d_dec, d_nres, c->stream));
     t.mark(5);
-    t.done(false);
+    t.done(0);
     return 0;
 }
 
@@ -424,15 +447,23 @@ int ft8gpu_get_timings(ft8gpu_ctx *c, ft8gpu_timings *out, int32_t *nruns) {
     for (int k = 0; k < n; k++) {
         const int slot = (int)((c->runs - 1 - k) % ft8gpu_ctx::kTimingSlots);
         hipEvent_t *e = c->ev[slot];
-        if (c->slot_overlapped[slot]) {
-            HIP_TRY(hipEventSynchronize(e[7]));
-            HIP_TRY(hipEventSynchronize(e[8 + 5]));
-            acc[0] += elapsed(e[0], e[1]);                                   // waterfall
-            acc[1] += elapsed(e[1], e[2]);                                   // sync: both halves
-            acc[2] += elapsed(e[8], e[9]) + elapsed(e[10], e[11]);           // heap: both halves (side stream, overlapped)
-            acc[3] += elapsed(e[3], e[4]) + elapsed(e[4], e[5]);             // decode: both launches
-            acc[4] += elapsed(e[12], e[13]) + elapsed(e[5], e[6]);           // spots: H0 (side, overlapped) + H1
-            acc[5] += elapsed(e[0], e[7]);
+        if (c->slot_form[slot] != 0) {
+            hipEvent_t *sd = e + ft8gpu_ctx::kSideEv0;
+            HIP_TRY(hipEventSynchronize(e[9]));
+            HIP_TRY(hipEventSynchronize(sd[5]));
+            acc[0] += elapsed(e[0], e[1]) + elapsed(e[2], e[3]);             // waterfall: both halves
+            acc[1] += elapsed(e[1], e[2]) + elapsed(e[3], e[4]);             // sync: both halves
+            acc[2] += elapsed(sd[0], sd[1]) + elapsed(sd[2], sd[3]);         // heap: both halves (side stream, overlapped)
+            if (c->slot_form[slot] == 1) {
+                acc[3] += elapsed(e[5], e[6]) + elapsed(e[6], e[7]);         // decode: both launches, back to back on the main stream
+                acc[4] += elapsed(sd[4], sd[5]) + elapsed(e[7], e[8]);       // spots: H0 (side, overlapped) + H1
+            } else {
+                // two LDPC kernels in flight on two streams: the stage's duration is the span from the first start to the last end
+                const float main_end = elapsed(e[5], e[6]), side_end = elapsed(e[5], sd[5]);
+                acc[3] += main_end > side_end ? main_end : side_end;
+                acc[4] += elapsed(e[7], e[8]);                               // spots(H0); spots(H1) is inside the side span
+            }
+            acc[5] += elapsed(e[0], e[9]);
             launches = 2;
         } else {
             HIP_TRY(hipEventSynchronize(e[5]));
@@ -613,11 +644,11 @@ int ft8gpu_waterfall(ft8gpu_ctx *c, const float *iq, int nframes, uint8_t *mag, 
     for (int f0 = 0; f0 < nframes; f0 += c->max_frames) {
         const int n = (nframes - f0 < c->max_frames) ? nframes - f0 : c->max_frames;
         if (flags & FT8GPU_DEVICE_PTRS) {
-            HIP_TRY(launch_waterfall(iq + f0 * frame_floats, mag + (size_t)f0 * kMagArray, c->d_tab, n, c->num_cus, c->stream));
+            HIP_TRY(launch_waterfall(iq + f0 * frame_floats, mag + (size_t)f0 * kMagArray, c->d_tab, n, c->num_cus, (c->debug_flags & FT8GPU_DBG_WF_OLD) ? 1 : 0, c->stream));
         } else {
             if (!c->d_iq) HIP_TRY(hipMalloc(&c->d_iq, (size_t)c->max_frames * frame_floats * sizeof(float)));
             HIP_TRY(hipMemcpyAsync(c->d_iq, iq + f0 * frame_floats, n * frame_floats * sizeof(float), hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(launch_waterfall(c->d_iq, c->d_mag, c->d_tab, n, c->num_cus, c->stream));
+            HIP_TRY(launch_waterfall(c->d_iq, c->d_mag, c->d_tab, n, c->num_cus, (c->debug_flags & FT8GPU_DBG_WF_OLD) ? 1 : 0, c->stream));
             HIP_TRY(hipMemcpyAsync(mag + (size_t)f0 * kMagArray, c->d_mag, (size_t)n * kMagArray, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
         }
@@ -637,7 +668,7 @@ int ft8gpu_find_sync(ft8gpu_ctx *c, const uint8_t *mag, int nframes, ft8gpu_cand
         ft8gpu_candidate *dc = dev ? cands + (size_t)f0 * mc : c->d_cands;
         int32_t *dn = dev ? counts + f0 : c->d_counts;
         if (!dev) HIP_TRY(hipMemcpyAsync(c->d_mag, mag + (size_t)f0 * kMagArray, (size_t)n * kMagArray, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(launch_sync(dm, c->d_lists, c->d_list_counts, nullptr, n, c->params.min_score, c->stream));
+        HIP_TRY(launch_sync(dm, c->d_lists, c->d_list_counts, nullptr, n, c->params.min_score, sync_old(c), c->stream));
         HIP_TRY(launch_heap(c->d_lists, c->d_list_counts, dc, dn, n, mc, c->stream));
         if (!dev) {
             HIP_TRY(hipMemcpyAsync(cands + (size_t)f0 * mc, dc, (size_t)n * mc * sizeof(ft8gpu_candidate), hipMemcpyDeviceToHost, c->stream));
@@ -659,7 +690,7 @@ int ft8gpu_score_map(ft8gpu_ctx *c, const uint8_t *mag, int nframes, int16_t *sc
         const uint8_t *dm = dev ? mag + (size_t)f0 * kMagArray : c->d_mag;
         int16_t *ds = dev ? scores + (size_t)f0 * kScoresPerFrame : c->d_scores;
         if (!dev) HIP_TRY(hipMemcpyAsync(c->d_mag, mag + (size_t)f0 * kMagArray, (size_t)n * kMagArray, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(launch_sync(dm, c->d_lists, c->d_list_counts, ds, n, c->params.min_score, c->stream));
+        HIP_TRY(launch_sync(dm, c->d_lists, c->d_list_counts, ds, n, c->params.min_score, sync_old(c), c->stream));
         if (!dev) {
             HIP_TRY(hipMemcpyAsync(scores + (size_t)f0 * kScoresPerFrame, ds, (size_t)n * kScoresPerFrame * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));

@@ -179,6 +179,202 @@ void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lis
     if (lane == 0) list_counts[(size_t)frame * kSublistsPerFrame + sub] = count;
 }
 
+// ---- second form of the sync kernel ----------------------------------------------------------------
+// Same maps, same results, fewer instructions and one memory latency instead of six:
+//   * build: every row a wave needs (its 5-6 consecutive t' plus one halo row either side, for the three
+//     Costas blocks: 24 dwords per lane) is requested up front; each row is widened to int16 once and slides
+//     through a (previous, current, next) window; the horizontal neighbours are taken from the SUM over the
+//     Costas blocks (a column shift commutes with that sum), not per block;
+//   * score: a lane owns FOUR adjacent frequency offsets (4 x 64 = 256 >= 249: one pass per time offset
+//     instead of four), read as 64-bit groups of int16 cells and added as packed pairs.  The offsets 4, 6, 2
+//     and 0 of the Costas pattern land on dword boundaries; 1, 5 and 3 are funnel-shifted out of two
+//     neighbouring dwords (v_alignbit).  The integer division by the number of averaged terms is NOT
+//     evaluated per position: trunc(num / n) >= min_score is decided exactly on the numerator
+//     (num >= T with T = min_score * n for min_score > 0, (min_score - 1) * n + 1 otherwise; saturating
+//     packed subtraction, sign bits), and only rows with a survivor -- about half of them hold one or two
+//     -- compute quotients, ranks (ballot + prefix popcount per cell column, scan order preserved) and
+//     store list entries.
+typedef uint32_t u32;
+
+__device__ __forceinline__ s16x2 as_s16x2(u32 v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ u32 as_u32(s16x2 v) { return __builtin_bit_cast(u32, v); }
+// ({hi, lo} >> 16) & 0xFFFFFFFF: (lo.hi16, hi.lo16) as (low half, high half)
+__device__ __forceinline__ u32 funnel16(u32 hi, u32 lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
+
+template <bool SCORE_MAP>
+__global__ __launch_bounds__(64 * kSyncWaves)
+void ft8_sync_kernel_v2(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lists,
+                        int32_t *__restrict__ list_counts, int16_t *__restrict__ score_map, int min_score) {
+    __shared__ __attribute__((aligned(16))) int16_t s_map[kMapRows * kMapPitch + 16];   // + the two dwords lane 63 reads past a row
+    __shared__ int s_navg[kT0Count];                             // terms averaged by ft8_sync_score() per time offset
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frame = blockIdx.x >> 2, seg = blockIdx.x & 3;
+    const int ts = seg >> 1, fs = seg & 1;
+    if (tid < kT0Count) s_navg[tid] = sync_navg(tid + kT0Min);   // (a loop of scalar branches when evaluated per row)
+
+    // ---- build the collapsed maps ------------------------------------------------------------------
+    {
+        const u32 *rows = reinterpret_cast<const u32 *>(mag + (size_t)frame * kMagArray + ts * 512 + fs * 256) + lane;
+        const int tq_begin = (wave * kTqCount) / kSyncWaves, tq_end = ((wave + 1) * kTqCount) / kSyncWaves;
+        const int ntq = tq_end - tq_begin;                       // 5 or 6
+        constexpr int kMaxTq = (kTqCount + kSyncWaves - 1) / kSyncWaves;   // 6
+        // row j of Costas block m is block b = tq_begin - 12 + 36 m - 1 + j, j in [0, ntq + 2)
+        u32 raw[3][kMaxTq + 2];
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int j = 0; j < kMaxTq + 2; ++j) {
+                const int b = tq_begin - 12 + 36 * m - 1 + j;   // wave-uniform
+                raw[m][j] = (j < ntq + 2 && b >= 0 && b < kNumBlocks) ? rows[(size_t)b * (kBlockStride / 4)] : 0u;
+            }
+        // (c0, c1) and (c2, c3) of a row as int16 pairs
+        auto widen = [](u32 v, s16x2 (&e)[2]) { e[0] = bytes2(0, v, 0x0c010c00u); e[1] = bytes2(0, v, 0x0c030c02u); };
+        s16x2 prev[3][2], cur[3][2], next[3][2];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) { widen(raw[m][0], prev[m]); widen(raw[m][1], cur[m]); }
+#pragma unroll
+        for (int i = 0; i < kMaxTq; ++i) {
+            if (i < ntq) {                                       // wave-uniform
+                const int tp = tq_begin + i - 12;                // t'
+                const s16x2 zero = { 0, 0 };
+                s16x2 C[2] = { zero, zero }, Up[2] = { zero, zero }, Dn[2] = { zero, zero };
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    widen(raw[m][i + 2], next[m]);
+                    const int b = tp + 36 * m;
+                    if (b < 0 || b >= kNumBlocks) continue;      // wave-uniform
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        C[h] += cur[m][h];
+                        Up[h] += b > 0 ? prev[m][h] : cur[m][h];                  // missing time neighbour: p - p = 0
+                        Dn[h] += b + 1 < kNumBlocks ? next[m][h] : cur[m][h];
+                    }
+                }
+                // horizontal neighbours of the summed cells (c0..c3 of this lane): left (c-1, c0, c1, c2), right (c1, c2, c3, c4)
+                const u32 c01 = as_u32(C[0]), c23 = as_u32(C[1]);
+                // lane 0 has no lower bin (p - p = 0: its left neighbour is c0 itself); lane 63's right neighbour (column 256) is never used
+                const u32 lprev = (u32)__builtin_amdgcn_update_dpp((int)(c01 << 16), (int)c23, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+                const u32 rnext = (u32)__builtin_amdgcn_update_dpp(0, (int)c01, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+                const s16x2 mid12 = as_s16x2(funnel16(c23, c01));                 // (c1, c2)
+                const s16x2 L[2] = { as_s16x2(funnel16(c01, lprev)), mid12 };     // (c-1, c0), (c1, c2)
+                const s16x2 R[2] = { mid12, as_s16x2(funnel16(rnext, c23)) };     // (c1, c2), (c3, c4)
+                s16x2 S[2], U[2], V[2], W[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    W[h] = C[h] - L[h];                                           // sum of dl
+                    U[h] = C[h] - Up[h];                                          // sum of du
+                    V[h] = C[h] - Dn[h];                                          // sum of dd
+                    S[h] = (W[h] + (C[h] - R[h])) + (U[h] + V[h]);                // sum of dl + dr + du + dd
+                }
+                auto store = [&](int row, s16x2 a, s16x2 b2) {
+                    uint2 v;
+                    v.x = as_u32(a);
+                    v.y = as_u32(b2);
+                    *reinterpret_cast<uint2 *>(s_map + row * kMapPitch + 4 * lane) = v;
+                };
+                if (tp >= -11 && tp < 29) store(kOffA + tp + 11, S[0], S[1]);
+                if (tp >= -12 && tp < 24) store(kOff0 + tp + 12, S[0] - U[0], S[1] - U[1]);
+                if (tp >= -9 && tp < 27)  store(kOff3 + tp + 9, S[0] - W[0], S[1] - W[1]);
+                if (tp >= -6 && tp < 30)  store(kOff6 + tp + 6, S[0] - V[0], S[1] - V[1]);
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) { prev[m][h] = cur[m][h]; cur[m][h] = next[m][h]; }
+            }
+        }
+        if (tid < 8) reinterpret_cast<u32 *>(s_map + kMapRows * kMapPitch)[tid] = 0u;   // the pad behind the last row
+    }
+    __syncthreads();
+
+    // ---- score all positions: lane = frequency offsets 4 lane .. 4 lane + 3 ----------------------------
+    const int sub = seg * kSyncWaves + wave;
+    uint32_t *my_list = lists + ((size_t)frame * kSublistsPerFrame + sub) * kSublistCap;
+    int count = 0;
+    const int t_begin = (wave * kT0Count) / kSyncWaves, t_end = ((wave + 1) * kT0Count) / kSyncWaves;
+    // sign-bit masks of the cells that are real positions (f0 < 249): all four up to lane 61, one in lane 62
+    const u32 vm_lo = lane < 62 ? 0x80008000u : (lane == 62 ? 0x00008000u : 0u);
+    const u32 vm_hi = lane < 62 ? 0x80008000u : 0u;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    for (int t0i = t_begin; t0i < t_end; ++t0i) {                // scan order: time_offset ascending
+        const int navg = __builtin_amdgcn_readfirstlane(s_navg[t0i]);
+        // trunc(num / navg) >= min_score  <=>  num >= T   (C division truncates toward zero; navg = 0 leaves the sum undivided)
+        int T = navg > 0 ? (min_score > 0 ? min_score * navg : (min_score - 1) * navg + 1) : min_score;
+        T = T > 32767 ? 32767 : (T < -32768 ? -32768 : T);       // |num| <= 21420: saturated thresholds mean never / always
+        const s16x2 Tpk = { (short)T, (short)T };
+        const u32 *pa0 = reinterpret_cast<const u32 *>(s_map + (kOffA + t0i + 0) * kMapPitch) + 2 * lane;   // t' = t0 + 1
+        const u32 *pa1 = reinterpret_cast<const u32 *>(s_map + (kOffA + t0i + 1) * kMapPitch) + 2 * lane;   // t0 + 2
+        const u32 *pa3 = reinterpret_cast<const u32 *>(s_map + (kOffA + t0i + 3) * kMapPitch) + 2 * lane;   // t0 + 4
+        const u32 *pa4 = reinterpret_cast<const u32 *>(s_map + (kOffA + t0i + 4) * kMapPitch) + 2 * lane;   // t0 + 5
+        const u32 *p0 = reinterpret_cast<const u32 *>(s_map + (kOff0 + t0i) * kMapPitch) + 2 * lane;
+        const u32 *p3 = reinterpret_cast<const u32 *>(s_map + (kOff3 + t0i) * kMapPitch) + 2 * lane;
+        const u32 *p6 = reinterpret_cast<const u32 *>(s_map + (kOff6 + t0i) * kMapPitch) + 2 * lane;
+        // cells f0 + off .. f0 + off + 3 of a row as two packed pairs; dword d of the lane's pointer holds cells 2d, 2d + 1
+        const u32 a0 = pa0[0], a1 = pa0[1], a2 = pa0[2];         // MA[t0+1], offset 1
+        const u32 b2 = pa1[2], b3 = pa1[3];                      // MA[t0+2], offset 4
+        const u32 c3 = pa3[3], c4 = pa3[4];                      // MA[t0+4], offset 6
+        const u32 d2 = pa4[2], d3 = pa4[3], d4 = pa4[4];         // MA[t0+5], offset 5
+        const u32 e1 = p0[1], e2 = p0[2], e3 = p0[3];            // M0[t0],   offset 3
+        const u32 f0_ = p3[0], f1 = p3[1];                       // M3[t0+3], offset 0
+        const u32 g1 = p6[1], g2 = p6[2];                        // M6[t0+6], offset 2
+        const s16x2 n_lo = ((as_s16x2(funnel16(e2, e1)) + as_s16x2(funnel16(a1, a0))) + as_s16x2(b2)) +
+                           ((as_s16x2(f0_) + as_s16x2(c3)) + as_s16x2(funnel16(d3, d2))) + as_s16x2(g1);
+        const s16x2 n_hi = ((as_s16x2(funnel16(e3, e2)) + as_s16x2(funnel16(a2, a1))) + as_s16x2(b3)) +
+                           ((as_s16x2(f1) + as_s16x2(c4)) + as_s16x2(funnel16(d4, d3))) + as_s16x2(g2);
+        // keep bit of a cell = NOT sign(num - T), restricted to real positions
+        const u32 k_lo = ~as_u32(__builtin_elementwise_sub_sat(n_lo, Tpk)) & vm_lo;
+        const u32 k_hi = ~as_u32(__builtin_elementwise_sub_sat(n_hi, Tpk)) & vm_hi;
+        const bool any = __builtin_amdgcn_ballot_w64((k_lo | k_hi) != 0u) != 0ull;
+        if (SCORE_MAP || any) {                                   // wave-uniform
+            const float rnavg = navg > 0 ? 1.0f / (float)navg : 1.0f;
+            // score /= navg (C int division, truncating toward zero) without an integer divide: with
+            // |score| <= 21*4*255 and navg <= 84 the quotient is either an integer or at least 1/84 away from
+            // one, while float(score)*fl(1/navg) is within 2e-3 of it, so adding 0.004 away from zero and
+            // truncating is exact.
+            auto quotient = [&](int num) {
+                const float fs_ = (float)num;
+                return (int)(fs_ * rnavg + __builtin_copysignf(0.004f, fs_));
+            };
+            const int num[4] = { (int)n_lo.x, (int)n_lo.y, (int)n_hi.x, (int)n_hi.y };
+            const bool keep[4] = { (k_lo & 0x8000u) != 0, (k_lo & 0x80000000u) != 0, (k_hi & 0x8000u) != 0, (k_hi & 0x80000000u) != 0 };
+            int score[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) score[j] = quotient(num[j]);
+            if (SCORE_MAP) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int f0 = 4 * lane + j;
+                    if (f0 < kF0Count)
+                        score_map[(size_t)frame * kScoresPerFrame + (seg * kT0Count + t0i) * kF0Count + f0] = (int16_t)score[j];
+                }
+            }
+            if (any) {
+                // scan order inside the row is f0 = 4 lane + j ascending: entries of lower lanes first, then lower j
+                unsigned long long bal[4];
+                int before = 0, total = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bal[j] = __builtin_amdgcn_ballot_w64(keep[j]);
+                    before += __popcll(bal[j] & lt_mask);
+                    total += __popcll(bal[j]);
+                }
+                int pos = count + before;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (keep[j]) {
+                        my_list[pos] = ((uint32_t)(score[j] & 0xFFFF) << 16) | ((uint32_t)t0i << 8) | (uint32_t)(4 * lane + j);
+                        ++pos;
+                    }
+                }
+                count += total;
+            }
+        }
+    }
+    if (lane == 0) list_counts[(size_t)frame * kSublistsPerFrame + sub] = count;
+}
+
 // ---- exact top-N selection -----------------------------------------------------------------
 // One wave per frame.  The min-heap lives in LDS as 64-bit words whose low 16 bits are the score
 // (the little-endian image of candidate_t).  Lanes fetch 64 list entries at a time; because the heap
@@ -438,10 +634,17 @@ void ft8_heap_kernel(const uint32_t *__restrict__ lists, const int32_t *__restri
 }  // namespace
 
 hipError_t launch_sync(const uint8_t *mag, uint32_t *lists, int32_t *list_counts, int16_t *score_map,
-                       int nframes, int min_score, hipStream_t s) {
+                       int nframes, int min_score, int old_form, hipStream_t s) {
     if (nframes < 1) return hipSuccess;
-    hipLaunchKernelGGL(ft8_sync_kernel, dim3(nframes * kSegments), dim3(64 * kSyncWaves), 0, s,
-                       mag, lists, list_counts, score_map, min_score);
+    if (old_form)
+        hipLaunchKernelGGL(ft8_sync_kernel, dim3(nframes * kSegments), dim3(64 * kSyncWaves), 0, s,
+                           mag, lists, list_counts, score_map, min_score);
+    else if (score_map)
+        hipLaunchKernelGGL(ft8_sync_kernel_v2<true>, dim3(nframes * kSegments), dim3(64 * kSyncWaves), 0, s,
+                           mag, lists, list_counts, score_map, min_score);
+    else
+        hipLaunchKernelGGL(ft8_sync_kernel_v2<false>, dim3(nframes * kSegments), dim3(64 * kSyncWaves), 0, s,
+                           mag, lists, list_counts, score_map, min_score);
     return hipGetLastError();
 }
 

@@ -83,6 +83,16 @@ __device__ __forceinline__ void pass16(c32 (&x)[16], const float2 (&twA)[4][3], 
 
 __device__ __forceinline__ int pad_idx(int p) { return p + 4 * (p >> 6); }
 
+// Layout of the SECOND exchange (between stages 3 and 4).  Stage 4 reads the four inputs 4c .. 4c+3 of
+// butterfly c as two 16-byte units; with the inputs contiguous (32 bytes per lane) every ds_read_b128 hits
+// each bank twice.  So the two halves of a butterfly's inputs live in two regions 260 units apart (unit =
+// two complex values = 16 bytes; 260 = 4 mod 8 staggers the regions by half a bank cycle), and the unit index
+// is XOR-swizzled with bits 4..5 of c:
+//     position of element 4c + e  =  2 * ((c ^ ((c >> 4) & 3)) + 260 * (e >> 1)) + (e & 1)      [complex values]
+// Both sides are then conflict-free: the 16 lanes of a ds_read_b128 group cover 16 distinct units mod 16, and
+// the 16 lanes of a ds_write_b64 group (four values of c >> 4, four of e) cover all 32 banks.
+constexpr int kHalfUnits = 260;
+
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -131,6 +141,7 @@ __device__ __forceinline__ const float4 *item_vec(const float *__restrict__ iq, 
     return reinterpret_cast<const float4 *>(base + plane * kNSamples) + i;
 }
 
+template <bool OLD_LAYOUT>
 __global__ __launch_bounds__(256)
 void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ mag,
                           const Ft8Tables *__restrict__ tab, int nitems, int nframes, int xcd_order) {
@@ -168,6 +179,11 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
 
     float2 *xb = s_x[wave];
     unsigned char *ob = s_out[wave];
+    // second exchange: this lane writes elements 64*b16 + j2 + 4a (c = 16*b16 + a, e = j2) and reads butterflies lane + 64 i
+    int wbase2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wbase2[r] = 32 * b16 + 2 * kHalfUnits * (j2 >> 1) + (j2 & 1) + 2 * (r ^ (b16 & 3));
+    const int rbase2 = 2 * (lane ^ ((lane >> 4) & 3));
 
     // software pipeline over work items: the next item's samples travel HBM -> registers while the
     // current item's rows are transformed, and are dropped into LDS at the top of the next round.
@@ -233,16 +249,16 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
             }
             pass16(x, twA2, twB2);              // stages 2, 3
 #pragma unroll
-            for (int a = 0; a < 16; ++a) xb[pad_idx(64 * b16 + j2 + 4 * a)] = make_float2(x[a].x, x[a].y);
+            for (int a = 0; a < 16; ++a)
+                xb[OLD_LAYOUT ? pad_idx(64 * b16 + j2 + 4 * a) : wbase2[a & 3] + 8 * (a >> 2)] = make_float2(x[a].x, x[a].y);
             wave_lds_sync();
 
             // stage 4 (L = 4, no twiddles): butterfly c = lane + 64*i holds bins k0+i (y0) and 256+k0+i (y1)
             unsigned q0[4], q1[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int c = lane + 64 * i;
-                const float4 *src = reinterpret_cast<const float4 *>(xb + pad_idx(4 * c));
-                const float4 v01 = src[0], v23 = src[1];
+                const float4 *src = reinterpret_cast<const float4 *>(xb + (OLD_LAYOUT ? pad_idx(4 * (lane + 64 * i)) : rbase2 + 128 * i));   // butterfly c = lane + 64 i
+                const float4 v01 = src[0], v23 = src[OLD_LAYOUT ? 1 : kHalfUnits];
                 const c32 a0 = { v01.x, v01.y }, a1 = { v01.z, v01.w }, a2 = { v23.x, v23.y }, a3 = { v23.z, v23.w };
                 const c32 t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = a1 - a3;
                 const c32 y0 = t0 + t2;
@@ -270,13 +286,14 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
 }  // namespace
 
 hipError_t launch_waterfall(const float *iq, uint8_t *mag, const Ft8Tables *tab, int nframes,
-                            int num_cus, hipStream_t s) {
+                            int num_cus, int old_layout, hipStream_t s) {
     const int nitems = nframes * kWfItemsPerFrame;
     int grid = num_cus * kWfGridPerCu;           // workgroups per CU (LDS-limited), persistent
     if (grid > nitems) grid = nitems;
     if (grid < 1) return hipSuccess;
     // XCD-aware order needs whole groups of 8 workgroups and enough frames to give every XCD work
     const int xcd_order = (grid % 8 == 0 && nframes >= 64) ? 1 : 0;
-    hipLaunchKernelGGL(ft8_waterfall_kernel, dim3(grid), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xcd_order);
+    if (old_layout) hipLaunchKernelGGL(ft8_waterfall_kernel<true>, dim3(grid), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xcd_order);
+    else hipLaunchKernelGGL(ft8_waterfall_kernel<false>, dim3(grid), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xcd_order);
     return hipGetLastError();
 }
