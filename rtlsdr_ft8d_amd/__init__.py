@@ -64,6 +64,7 @@ ABI_SYMBOLS = [
     "ft8gpu_synth_frames", "ft8gpu_synth_frames_at", "ft8gpu_rx_decimate", "ft8gpu_pskreporter_datagrams", "ft8gpu_format_spots",
     "ft8gpu_dev_alloc", "ft8gpu_dev_free", "ft8gpu_memcpy_h2d", "ft8gpu_memcpy_d2h",
     "ft8gpu_set_debug_flags", "ft8gpu_decode_batch_multi", "ft8gpu_decode_batch_multi_dev",
+    "ft8_find_sync", "ft8_decode", "ft8_encode", "pack77",            # ft8_lib level (include/ft8_lib/ft8/*.h)
     "initFFTW", "freeFFTW", "ft8_subsystem", "ft8gpu_read_raw_iq", "ft8gpu_read_c2", "ft8gpu_write_raw_iq",
 ]
 

@@ -5,10 +5,15 @@
  *   * the encoder tooling the self-test uses (pack77 for standard messages, ft8_encode:
  *     rtlsdr_ft8d.c:924-934; ft8_lib pack.c / encode.c / crc.c)
  *   * the .iq / .c2 replay readers and the .iq writer (rtlsdr_ft8d.c:744-856)
+ *   * the ft8_lib-level symbols the reference's own ft8_subsystem() calls (ft8_find_sync, ft8_decode:
+ *     rtlsdr_ft8d.c:1450, :1476; pack77, ft8_encode: :927, :934), declared in the headers under include/ft8_lib/ft8
  * No GPU code here: everything goes through the C ABI of include/ft8gpu.h.
  */
 #define _GNU_SOURCE
 #include "../../include/ft8gpu.h"
+#include "../../include/ft8_lib/ft8/decode.h"
+#include "../../include/ft8_lib/ft8/pack.h"
+#include "../../include/ft8_lib/ft8/encode.h"
 #include "ft8_tables.h"
 
 #include <math.h>
@@ -22,6 +27,15 @@
  * ------------------------------------------------------------------------------------------- */
 static ft8gpu_ctx *g_ctx = NULL;
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+/* state of the ft8_lib-level entries further down (they share the context) */
+static struct {
+    const uint8_t *mag;                     /* waterfall of the remembered ft8_find_sync() call */
+    uint64_t mag_sum;                       /* its content checksum */
+    int ncand, cap, min_score;
+    int decoded_iters;                      /* max_iterations the remembered statuses were computed with, 0 = none yet */
+    ft8gpu_candidate cands[FT8GPU_ABS_MAX_CANDIDATES];
+    ft8gpu_decode_status st[FT8GPU_ABS_MAX_CANDIDATES];
+} g_l2;
 
 static int global_ctx_init(void) {
     if (g_ctx) return 0;
@@ -63,7 +77,9 @@ void ft8_subsystem(float *iSamples, float *qSamples, uint32_t samples_len,
     memcpy(iq, iSamples, sizeof(float) * FT8GPU_NSAMPLES);
     memcpy(iq + FT8GPU_NSAMPLES, qSamples, sizeof(float) * FT8GPU_NSAMPLES);
     int32_t n = 0;
-    if (ft8gpu_decode_batch(g_ctx, iq, 1, decodes, &n, FT8GPU_HOST_PTRS) != 0) {
+    const ft8gpu_params ref_params = { FT8GPU_K_MIN_SCORE, FT8GPU_K_MAX_CANDIDATES, FT8GPU_K_LDPC_ITERS };   /* rtlsdr_ft8d.h:43-45 */
+    g_l2.mag = NULL;                                       /* (the ft8_lib-level entries below share this context) */
+    if (ft8gpu_set_params(g_ctx, &ref_params) != 0 || ft8gpu_decode_batch(g_ctx, iq, 1, decodes, &n, FT8GPU_HOST_PTRS) != 0) {
         fprintf(stderr, "ft8gpu: decode failed: %s\n", ft8gpu_last_error());
         n = 0;
     }
@@ -71,6 +87,131 @@ void ft8_subsystem(float *iSamples, float *qSamples, uint32_t samples_len,
     free(iq);
     pthread_mutex_unlock(&g_lock);
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * ft8_lib level: ft8_find_sync / ft8_decode as the reference calls them (rtlsdr_ft8d.c:1450, :1476)
+ *
+ * Both run on the process-global context above.  The reference calls ft8_find_sync() once per frame and
+ * then ft8_decode() once per candidate of the returned list (:1465-1485); a GPU launch per candidate would be
+ * all latency, so the first ft8_decode() after an ft8_find_sync() on the same waterfall decodes the WHOLE list
+ * in one launch and the following calls are answered from that result.  ft8_decode() is a pure function of
+ * (waterfall, candidate, max_iterations): a candidate that is not in the remembered list, another waterfall or
+ * changed waterfall bytes simply take the one-candidate path.
+ * ------------------------------------------------------------------------------------------- */
+
+static uint64_t waterfall_checksum(const uint8_t *mag) {
+    const uint64_t *w = (const uint64_t *)(const void *)mag;      /* MAG_ARRAY is a multiple of 8; rows are byte arrays */
+    uint64_t a = 0x9E3779B97F4A7C15ull, b = 0;
+    if (((uintptr_t)mag & 7) != 0) {
+        for (int i = 0; i < FT8GPU_MAG_ARRAY; i++) { a = (a ^ mag[i]) * 0x100000001B3ull; }
+        return a;
+    }
+    for (int i = 0; i < FT8GPU_MAG_ARRAY / 8; i++) { a += w[i]; b += a; }
+    return a ^ (b << 1);
+}
+
+static int waterfall_supported(const waterfall_t *wf) {
+    return wf && wf->mag && wf->num_blocks == FT8GPU_NUM_BLOCKS && wf->num_bins == FT8GPU_NUM_BIN && wf->time_osr == 2 &&
+           wf->freq_osr == 2 && wf->block_stride == 4 * FT8GPU_NUM_BIN && wf->protocol == PROTO_FT8;
+}
+
+int ft8_find_sync(const waterfall_t *power, int num_candidates, candidate_t heap[], int min_score) {
+    if (!waterfall_supported(power) || !heap || num_candidates < 1 || num_candidates > FT8GPU_ABS_MAX_CANDIDATES) {
+        fprintf(stderr, "ft8gpu: ft8_find_sync: unsupported waterfall geometry or candidate count (92 x 2 x 2 x 256, PROTO_FT8, 1..%d)\n",
+                FT8GPU_ABS_MAX_CANDIDATES);
+        return 0;
+    }
+    int32_t count = 0;
+    pthread_mutex_lock(&g_lock);
+    g_l2.mag = NULL;
+    if (global_ctx_init() == 0) {
+        const ft8gpu_params p = { min_score, num_candidates, FT8GPU_K_LDPC_ITERS };
+        if (ft8gpu_set_params(g_ctx, &p) != 0 ||
+            ft8gpu_find_sync(g_ctx, power->mag, 1, g_l2.cands, &count, FT8GPU_HOST_PTRS) != 0) {
+            fprintf(stderr, "ft8gpu: ft8_find_sync failed: %s\n", ft8gpu_last_error());
+            count = 0;
+        } else {
+            memcpy(heap, g_l2.cands, sizeof(candidate_t) * (size_t)count);      /* same 8-byte layout */
+            g_l2.mag = power->mag;
+            g_l2.mag_sum = waterfall_checksum(power->mag);
+            g_l2.ncand = count;
+            g_l2.cap = num_candidates;
+            g_l2.min_score = min_score;
+            g_l2.decoded_iters = 0;
+        }
+    }
+    pthread_mutex_unlock(&g_lock);
+    return count;
+}
+
+bool ft8_decode(const waterfall_t *power, const candidate_t *cand, message_t *message, int max_iterations,
+                decode_status_t *status) {
+    decode_status_t local;
+    if (!status) status = &local;
+    memset(status, 0, sizeof *status);
+    status->ldpc_errors = FTX_LDPC_M;                      /* "nothing satisfied": the value bp_decode starts from */
+    if (!waterfall_supported(power) || !cand || !message || max_iterations < 1) {
+        fprintf(stderr, "ft8gpu: ft8_decode: unsupported waterfall geometry or arguments\n");
+        return false;
+    }
+    _Static_assert(sizeof(candidate_t) == sizeof(ft8gpu_candidate), "candidate_t layout");
+    const ft8gpu_decode_status *res = NULL;
+    ft8gpu_decode_status one;
+    pthread_mutex_lock(&g_lock);
+    if (global_ctx_init() == 0) {
+        int idx = -1;
+        if (g_l2.mag == power->mag)
+            for (int i = 0; i < g_l2.ncand; i++)
+                if (!memcmp(&g_l2.cands[i], cand, sizeof *cand)) { idx = i; break; }
+        if (idx >= 0 && g_l2.decoded_iters != max_iterations) {
+            /* first ft8_decode() of this list (or another iteration count): one launch for all candidates */
+            const ft8gpu_params p = { g_l2.min_score, g_l2.cap, max_iterations };
+            const int32_t n = g_l2.ncand;
+            if (waterfall_checksum(power->mag) != g_l2.mag_sum) idx = -1;        /* the bytes changed since ft8_find_sync() */
+            else if (ft8gpu_set_params(g_ctx, &p) != 0 ||
+                     ft8gpu_decode_candidates(g_ctx, power->mag, g_l2.cands, &n, 1, g_l2.st, FT8GPU_HOST_PTRS) != 0) {
+                fprintf(stderr, "ft8gpu: ft8_decode failed: %s\n", ft8gpu_last_error());
+                idx = -2;
+            } else g_l2.decoded_iters = max_iterations;
+        }
+        if (idx >= 0) res = &g_l2.st[idx];
+        else if (idx == -1) {                              /* not from the remembered list: decode this one candidate */
+            const ft8gpu_params p = { -32768, 1, max_iterations };
+            const int32_t n = 1;
+            ft8gpu_candidate c1;
+            memcpy(&c1, cand, sizeof c1);
+            g_l2.mag = NULL;                               /* the context's parameters no longer describe the list */
+            if (ft8gpu_set_params(g_ctx, &p) != 0 ||
+                ft8gpu_decode_candidates(g_ctx, power->mag, &c1, &n, 1, &one, FT8GPU_HOST_PTRS) != 0)
+                fprintf(stderr, "ft8gpu: ft8_decode failed: %s\n", ft8gpu_last_error());
+            else res = &one;
+        }
+    }
+    bool ok = false;
+    if (res) {
+        status->ldpc_errors = res->ldpc_errors;
+        status->crc_extracted = res->crc_extracted;
+        status->crc_calculated = res->crc_calculated;
+        status->unpack_status = res->unpack_status;
+        if (res->ok) {
+            memcpy(message->text, res->text, sizeof message->text);
+            message->hash = res->crc_extracted;
+            ok = true;
+        }
+    }
+    pthread_mutex_unlock(&g_lock);
+    return ok;
+}
+
+int pack77(const char *msg, uint8_t *c77) {
+    uint8_t p[10];
+    if (ft8gpu_pack77_std(msg, p) != 0) return -1;
+    memcpy(c77, p, 10);
+    c77[10] = c77[11] = 0;                                 /* FTX_LDPC_K_BYTES = 12 */
+    return 0;
+}
+
+void ft8_encode(const uint8_t *payload, uint8_t *tones) { ft8gpu_encode(payload, tones); }
 
 /* ---------------------------------------------------------------------------------------------
  * encoder tooling: pack77 (standard messages) + CRC-14 + LDPC(174,91) generator + tone mapping

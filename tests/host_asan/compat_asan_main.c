@@ -12,6 +12,9 @@
 #include <unistd.h>
 
 #include "ft8gpu.h"
+#include "ft8_lib/ft8/decode.h"
+#include "ft8_lib/ft8/encode.h"
+#include "ft8_lib/ft8/pack.h"
 
 int ft8gpu_create(ft8gpu_ctx **out, int device, int max_frames, const ft8gpu_params *params) {
     (void)device; (void)max_frames; (void)params;
@@ -22,6 +25,17 @@ void ft8gpu_destroy(ft8gpu_ctx *ctx) { (void)ctx; }
 const char *ft8gpu_last_error(void) { return "host sanitizer harness: no GPU half linked"; }
 int ft8gpu_decode_batch(ft8gpu_ctx *ctx, const float *iq, int nframes, struct decoder_results *decodes, int32_t *n_results, int flags) {
     (void)ctx; (void)iq; (void)nframes; (void)decodes; (void)n_results; (void)flags;
+    return -1;
+}
+
+int ft8gpu_set_params(ft8gpu_ctx *ctx, const ft8gpu_params *params) { (void)ctx; (void)params; return -1; }
+int ft8gpu_find_sync(ft8gpu_ctx *ctx, const uint8_t *mag, int nframes, ft8gpu_candidate *cands, int32_t *counts, int flags) {
+    (void)ctx; (void)mag; (void)nframes; (void)cands; (void)counts; (void)flags;
+    return -1;
+}
+int ft8gpu_decode_candidates(ft8gpu_ctx *ctx, const uint8_t *mag, const ft8gpu_candidate *cands, const int32_t *counts,
+                             int nframes, ft8gpu_decode_status *status, int flags) {
+    (void)ctx; (void)mag; (void)cands; (void)counts; (void)nframes; (void)status; (void)flags;
     return -1;
 }
 
@@ -104,6 +118,26 @@ int main(int argc, char **argv) {
     CHECK(n == 0 && !memcmp(before, d, sizeof before));
     freeFFTW();
     freeFFTW();
+    /* the ft8_lib-level entries without a GPU: refuse quietly, leave the caller's buffers alone */
+    uint8_t c77[FTX_LDPC_K_BYTES], tn[FT8_NN];
+    CHECK(pack77("CQ K1JT FN20QI", c77) == 0 && !memcmp(c77, kat_packed, 10) && c77[10] == 0 && c77[11] == 0);
+    CHECK(pack77("not a message", c77) < 0);
+    ft8_encode(c77, tn);
+    CHECK(!memcmp(tn, tones, 0) && tn[0] == 3 && tn[78] == 2);
+    uint8_t *mag = calloc(FT8GPU_MAG_ARRAY, 1);
+    CHECK(mag != NULL);
+    waterfall_t wf = { .num_blocks = 92, .num_bins = 256, .time_osr = 2, .freq_osr = 2, .mag = mag, .block_stride = 1024, .protocol = PROTO_FT8 };
+    candidate_t heap[8];
+    memset(heap, 0x11, sizeof heap);
+    CHECK(ft8_find_sync(&wf, 8, heap, 10) == 0);
+    message_t msg;
+    decode_status_t st;
+    CHECK(!ft8_decode(&wf, &heap[0], &msg, 20, &st) && st.ldpc_errors == FTX_LDPC_M);
+    CHECK(!ft8_decode(&wf, &heap[0], &msg, 20, NULL));
+    wf.num_blocks = 91;
+    CHECK(ft8_find_sync(&wf, 8, heap, 10) == 0 && !ft8_decode(&wf, &heap[0], &msg, 20, &st));
+    CHECK(ft8_find_sync(NULL, 8, heap, 10) == 0 && !ft8_decode(NULL, NULL, NULL, 0, NULL));
+    free(mag);
     free(I); free(Q); free(I2); free(Q2); free(d); free(text);
     puts("compat_asan ok");
     return 0;

@@ -23,11 +23,15 @@ def ft8():
 
 
 def declared_functions():
-    src = open(os.path.join(ROOT, "include", "ft8gpu.h")).read()
+    src = ""
+    for d, _, files in os.walk(os.path.join(ROOT, "include")):       # ft8gpu.h and the ft8_lib-level headers
+        for f in sorted(files):
+            if f.endswith(".h"):
+                src += open(os.path.join(d, f)).read() + "\n"
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = re.sub(r"^\s*#.*$", "", src, flags=re.M)              # preprocessor lines declare nothing
     names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", src)
-    return sorted(set(n for n in names if n.startswith("ft8") or n in ("initFFTW", "freeFFTW")))
+    return sorted(set(n for n in names if n.startswith("ft8") or n in ("initFFTW", "freeFFTW", "pack77")))
 
 
 def test_exports_every_declared_symbol(ft8):

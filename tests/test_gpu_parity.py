@@ -526,6 +526,85 @@ def test_c_caller_self_test_and_file_replay(oracle, tmp_path):
     assert n == 1 and f"     {int(dec[0]['snr']):2d} {int(dec[0]['freq']):8d} {dec[0]['call'].decode():>10s} {dec[0]['loc'].decode():>6s}" in out.stdout
 
 
+def test_ft8_lib_level_c_caller(tmp_path):
+    """examples/ft8_lib_level.c: the reference's own candidate loop (rtlsdr_ft8d.c:1438-1523) written against
+    the ft8_lib-level headers under include/ft8_lib/ft8/ and the symbols ft8_find_sync / ft8_decode / pack77 /
+    ft8_encode of libft8gpu.so -- must give the records ft8_subsystem gives"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "ft8_lib_level")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu17", "-Wall", "-Wextra", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "ft8_lib_level.c"),
+                           "-L", os.path.join(root, "rtlsdr_ft8d_amd"), "-lft8gpu",
+                           "-Wl,-rpath," + os.path.join(root, "rtlsdr_ft8d_amd"), "-lm", "-o", exe])
+    out = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ft8_lib-level path == ft8_subsystem" in out.stdout and "K1JT" in out.stdout and "DL1ABC" in out.stdout
+
+
+def test_ft8_lib_level_symbols_match_the_oracle(oracle, frames, oracle_mags):
+    """ft8_find_sync / ft8_decode (rtlsdr_ft8d.c:1450, :1476) through ctypes: candidate lists and every
+    candidate's message / status against the oracle, including the paths that bypass the remembered list
+    (a candidate that was not returned by ft8_find_sync, a waterfall changed in place, another iteration count)"""
+    import ctypes as C
+    import rtlsdr_ft8d_amd as ft8
+
+    class Waterfall(C.Structure):
+        _fields_ = [("max_blocks", C.c_int), ("num_blocks", C.c_int), ("num_bins", C.c_int), ("time_osr", C.c_int),
+                    ("freq_osr", C.c_int), ("mag", C.c_void_p), ("block_stride", C.c_int), ("protocol", C.c_int)]
+
+    class Message(C.Structure):
+        _fields_ = [("text", C.c_char * 25), ("hash", C.c_uint16)]
+
+    class Status(C.Structure):
+        _fields_ = [("ldpc_errors", C.c_int), ("crc_extracted", C.c_uint16), ("crc_calculated", C.c_uint16), ("unpack_status", C.c_int)]
+
+    L = ft8.load_library()
+    L.ft8_find_sync.argtypes = [C.POINTER(Waterfall), C.c_int, C.c_void_p, C.c_int]
+    L.ft8_decode.argtypes = [C.POINTER(Waterfall), C.c_void_p, C.POINTER(Message), C.c_int, C.POINTER(Status)]
+    L.ft8_decode.restype = C.c_bool
+
+    def check(mag, cand, iters):
+        m, st = Message(), Status()
+        ok = L.ft8_decode(C.byref(wf), cand.ctypes.data, C.byref(m), iters, C.byref(st))
+        r = oracle.decode(mag, cand, iters)
+        assert bool(ok) == r["ok"] and st.ldpc_errors == r["ldpc_errors"]
+        if r["ldpc_errors"] == 0:
+            assert (st.crc_extracted, st.crc_calculated) == (r["crc_extracted"], r["crc_calculated"])
+        if r["ok"]:
+            assert m.text.decode() == r["text"] and m.hash == r["hash"] and st.unpack_status == r["unpack_status"]
+        return bool(ok)
+
+    nok = 0
+    for k in (0, 3, 4, 5):                                   # self-test, 20 / 40 / 60 signals
+        mag = oracle_mags[k].copy()
+        wf = Waterfall(0, 92, 256, 2, 2, mag.ctypes.data, 1024, 1)      # PROTO_FT8 = 1
+        heap = np.zeros(120, ft8.CAND_DTYPE)
+        n = L.ft8_find_sync(C.byref(wf), 120, heap.ctypes.data, 10)
+        ref = oracle.find_sync(mag)
+        assert n == len(ref) and np.array_equal(heap[:n], ref)
+        for c in range(n):                                   # the remembered list: one launch, then lookups
+            nok += check(mag, heap[c:c + 1], 20)
+        for c in (0, n // 2):                                # another iteration count re-decodes the list
+            check(mag, heap[c:c + 1], 3)
+        other = heap[:1].copy()                              # a candidate ft8_find_sync never returned
+        other["freq_offset"] += 1
+        check(mag, other, 20)
+        mag[1000:60000] = np.random.default_rng(k).integers(0, 255, 59000, dtype=np.uint8)   # same buffer, new bytes
+        for c in (0, 1, n - 1):
+            check(mag, heap[c:c + 1], 7)
+    assert nok > 30
+    # geometry the kernels are not built for is refused
+    bad = Waterfall(0, 93, 256, 2, 2, oracle_mags[0].ctypes.data, 1024, 1)
+    assert L.ft8_find_sync(C.byref(bad), 120, np.zeros(120, ft8.CAND_DTYPE).ctypes.data, 10) == 0
+    # and the drop-in ft8_subsystem still uses the reference's constants afterwards
+    i, q = frames[3][1]
+    dec, n = ft8.ft8_subsystem(i, q)
+    rdec, rn = oracle.subsystem(i, q)
+    assert n == rn and dec.tobytes() == rdec.tobytes()
+
+
 @pytest.mark.parametrize("cap,min_score,iters", [(33, 10, 20), (7, 12, 5), (250, 8, 20)])
 def test_end_to_end_other_parameters(oracle, gpu_decoder, frames, cap, min_score, iters):
     """run-time forms of K_MAX_CANDIDATES / K_MIN_SCORE / K_LDPC_ITERS (rtlsdr_ft8d.h:43-45), including
