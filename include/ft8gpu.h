@@ -99,9 +99,10 @@ typedef struct {
     float decode_ms;      /* LLR + LDPC BP + CRC + unpack */
     float spots_ms;       /* dedup + CQ spot fill */
     float total_ms;       /* first kernel start to last kernel end */
-    int32_t launches_per_stage; /* 1, or 2 when a large batch is processed as two overlapped halves: heap and
-                                   spots of one half then run on a side stream under the other half's decode,
-                                   and the per-stage figures are sums over both launches */
+    int32_t launches_per_stage; /* 1, or 2 when a large batch is processed as two overlapped parts (a small first
+                                   part and the rest): heap and spots of one part then run on a side stream under
+                                   the other part's kernels, and the per-stage figures are sums over both launches
+                                   (the waterfall stays one launch) */
 } ft8gpu_timings;
 
 /* ---- lifecycle: replaces initFFTW()/freeFFTW(), rtlsdr_ft8d.c:314-347 ----------------------- */
@@ -126,7 +127,7 @@ int  ft8gpu_set_stream(ft8gpu_ctx *ctx, void *hip_stream);
                                          uses (no exact error count: ldpc_errors is 0 or 83) */
 #define FT8GPU_DBG_NO_OVERLAP     4u  /* one launch per stage for the whole batch: no two-half overlap, no chunked upload */
 #define FT8GPU_DBG_SYNC_OLD       8u  /* the first form of the sync kernel (kept for A/B measurements of the second) */
-#define FT8GPU_DBG_DECODE_TWO_STREAMS 16u /* experiment: the second half-batch's LDPC kernel on the side stream */
+/* bits 8..11: size of the first part of an overlapped batch in sixteenths of the batch (0 = default 2) */
 #define FT8GPU_DBG_WF_OLD         32u  /* waterfall kernel with the first (bank-conflicting) layout of its second exchange (A/B) */
 int  ft8gpu_set_debug_flags(ft8gpu_ctx *ctx, unsigned flags);
 int  ft8gpu_set_params(ft8gpu_ctx *ctx, const ft8gpu_params *params);

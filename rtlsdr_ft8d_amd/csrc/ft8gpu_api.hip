@@ -100,7 +100,7 @@ struct ft8gpu_ctx {
     hipEvent_t ev[kTimingSlots][kEvPerSlot]{};   // ring of per-run stage events (no host sync while timing):
                                                  // 0..9 on the main stream, 10..15 on the side stream
     long runs = 0;                         // pipeline runs recorded since timing was enabled
-    int slot_form[kTimingSlots]{};         // which form of the pipeline a slot recorded: 0 plain, 1 two halves, 2 two halves on two streams
+    int slot_form[kTimingSlots]{};         // which form of the pipeline a slot recorded: 0 one launch per stage, 1 two parts
     hipStream_t side = nullptr;            // carries the serial kernels (heap, spots) of one half-batch
                                            // while the main stream works on the other half
     hipEvent_t dep[6]{};                   // cross-stream dependencies (no timing)
@@ -187,21 +187,27 @@ float elapsed(hipEvent_t a, hipEvent_t b) {
     return ms;
 }
 
-// Large batches: the two serial kernels (exact heap replay, spot collection) keep only one lane per
-// frame busy, so they run on a side stream for one half of the batch while the main stream runs the
-// throughput kernels of the other half:
-//   main: waterfall(H0) sync(H0) waterfall(H1) sync(H1) ..wait heap(H0).. decode(H0) ..wait heap(H1).. decode(H1) spots(H1)
-//   side:                        heap(H0)                                    heap(H1)              spots(H0)
-// heap(H0) hides under the front end of the second half, heap(H1) and spots(H0) under the LDPC kernels.
-// With FT8GPU_DBG_DECODE_TWO_STREAMS the second half's LDPC kernel and spots follow heap(H1) on the side
-// stream instead, so they fill the CUs the first half's kernel leaves idle while its last blocks drain.
+// Large batches: the two serial kernels (exact heap replay, spot collection) keep only one lane per frame
+// busy, so the batch is cut into a SMALL first part A and the rest B, and their serial kernels run on a side
+// stream under the throughput kernels of the other part:
+//   main: waterfall(all) sync(A) sync(B) ..wait heap(A).. decode(A) ..wait heap(B).. decode(B) spots(B)
+//   side:                 heap(A)         heap(B)                     spots(A)
+// heap(A) (a few hundred frames, register form of the replay) hides under sync(B), heap(B) under decode(A),
+// spots(A) under decode(B); what stays exposed is spots(B) and one extra LDPC-kernel tail.  (Measured
+// alternatives, profiles/r02_ab_kernels.json: equal halves with heap(A) under sync(B) or under a per-half
+// waterfall cost 0.1-0.16 ms more; everything in sequence, one launch per stage, costs the heap's 0.24 ms.)
 int run_pipeline_overlapped(ft8gpu_ctx *c, const float *d_iq, int n, struct decoder_results *d_dec, int32_t *d_nres) {
     StageTimer t(c);
     const ft8gpu_params &p = c->params;
     const int mc = p.max_candidates;
-    const int n0 = n / 2, n1 = n - n0;
-    const size_t lo = (size_t)n0;                                   // frame offset of the second half
-    const float *iq1 = d_iq + lo * 2 * (size_t)kNSamples;
+    // size of part A in 1/16ths of the batch (debug knob in flag bits 8..11), whole blocks of 64 frames.  Swept at 4096
+    // frames in one session: 1/16 4.99 ms, 2/16 5.03, 4/16 5.03, 8/16 5.22; one launch per stage 5.14.
+    const int sixteenths = ((c->debug_flags >> 8) & 15) ? (int)((c->debug_flags >> 8) & 15) : (n >= 2048 ? 1 : 2);
+    int n0 = ((n * sixteenths / 16) + 63) & ~63;
+    if (n0 < 64) n0 = 64;
+    if (n0 > n - 64) n0 = n / 2;
+    const int n1 = n - n0;
+    const size_t lo = (size_t)n0;                                   // frame offset of part B
     uint8_t *mag1 = c->d_mag + lo * kMagArray;
     uint32_t *lists1 = c->d_lists + lo * kSublistsPerFrame * kSublistCap;
     int32_t *lc1 = c->d_list_counts + lo * kSublistsPerFrame;
@@ -209,23 +215,20 @@ int run_pipeline_overlapped(ft8gpu_ctx *c, const float *d_iq, int n, struct deco
     int32_t *counts1 = c->d_counts + lo;
     ft8gpu_decode_status *st1 = c->d_status + lo * mc;
     const int wf_old = (c->debug_flags & FT8GPU_DBG_WF_OLD) ? 1 : 0;
-    const bool two_streams = (c->debug_flags & FT8GPU_DBG_DECODE_TWO_STREAMS) != 0;
-    hipEvent_t *E = c->dep;          // 0: sync(H0) done  1: sync(H1) done  2: heap(H0)  3: heap(H1)  4: decode(H0)  5: side stream done
+    hipEvent_t *E = c->dep;          // 0: sync(A) done  1: sync(B) done  2: heap(A)  3: heap(B)  4: decode(A)  5: side stream done
 
-    // main stream events: 0 wf(H0) 1 sync(H0) 2 wf(H1) 3 sync(H1) 4 | 5 decode(H0) 6 [decode(H1) 7 spots(H1) 8] | 9 end
-    // side stream events: 0 heap(H0) 1 | 2 heap(H1) 3 | 4 spots(H0) or decode(H1)+spots(H1) 5
+    // main stream events: 0 waterfall 1 sync(A) 2 sync(B) 3 | 4 decode(A) 5 decode(B) 6 spots(B) 7 | 8 end
+    // side stream events: 0 heap(A) 1 | 2 heap(B) 3 | 4 spots(A) 5
     t.mark(0);
-    HIP_TRY(launch_waterfall(d_iq, c->d_mag, c->d_tab, n0, c->num_cus, wf_old, c->stream));
+    HIP_TRY(launch_waterfall(d_iq, c->d_mag, c->d_tab, n, c->num_cus, wf_old, c->stream));
     t.mark(1);
     HIP_TRY(launch_sync(c->d_mag, c->d_lists, c->d_list_counts, nullptr, n0, p.min_score, sync_old(c), c->stream));
     HIP_TRY(hipEventRecord(E[0], c->stream));
     t.mark(2);
-    HIP_TRY(launch_waterfall(iq1, mag1, c->d_tab, n1, c->num_cus, wf_old, c->stream));
-    t.mark(3);
     HIP_TRY(launch_sync(mag1, lists1, lc1, nullptr, n1, p.min_score, sync_old(c), c->stream));
     HIP_TRY(hipEventRecord(E[1], c->stream));
-    t.mark(4);
-    // side stream: heap(H0), heap(H1)
+    t.mark(3);
+    // side stream: heap(A), heap(B)
     HIP_TRY(hipStreamWaitEvent(c->side, E[0], 0));
     t.mark_side(0);
     HIP_TRY(launch_heap(c->d_lists, c->d_list_counts, c->d_cands, c->d_counts, n0, mc, c->side));
@@ -236,37 +239,26 @@ int run_pipeline_overlapped(ft8gpu_ctx *c, const float *d_iq, int n, struct deco
     HIP_TRY(launch_heap(lists1, lc1, cands1, counts1, n1, mc, c->side));
     t.mark_side(3);
     HIP_TRY(hipEventRecord(E[3], c->side));
-    // main stream: decode(H0)
+    // main stream: decode(A), decode(B), spots(B)
     HIP_TRY(hipStreamWaitEvent(c->stream, E[2], 0));
-    t.mark(5);
+    t.mark(4);
     HIP_TRY(launch_decode(c->d_mag, c->d_cands, c->d_counts, c->d_status, n0, mc, p.ldpc_iters, false, force_ieee(c), c->stream));
+    t.mark(5);
+    HIP_TRY(hipEventRecord(E[4], c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, E[3], 0));
+    HIP_TRY(launch_decode(mag1, cands1, counts1, st1, n1, mc, p.ldpc_iters, false, force_ieee(c), c->stream));
     t.mark(6);
-    if (two_streams) {
-        t.mark_side(4);
-        HIP_TRY(launch_decode(mag1, cands1, counts1, st1, n1, mc, p.ldpc_iters, false, force_ieee(c), c->side));
-        HIP_TRY(launch_spots(cands1, counts1, st1, n1, mc, p.min_score, d_dec + lo * kMaxMessages, d_nres + lo, c->side));
-        t.mark_side(5);
-        HIP_TRY(hipEventRecord(E[5], c->side));
-        t.mark(7);
-        HIP_TRY(launch_spots(c->d_cands, c->d_counts, c->d_status, n0, mc, p.min_score, d_dec, d_nres, c->stream));
-        t.mark(8);
-    } else {
-        HIP_TRY(hipEventRecord(E[4], c->stream));
-        HIP_TRY(hipStreamWaitEvent(c->stream, E[3], 0));
-        HIP_TRY(launch_decode(mag1, cands1, counts1, st1, n1, mc, p.ldpc_iters, false, force_ieee(c), c->stream));
-        t.mark(7);
-        // side stream: spots(H0) while decode(H1) runs
-        HIP_TRY(hipStreamWaitEvent(c->side, E[4], 0));
-        t.mark_side(4);
-        HIP_TRY(launch_spots(c->d_cands, c->d_counts, c->d_status, n0, mc, p.min_score, d_dec, d_nres, c->side));
-        t.mark_side(5);
-        HIP_TRY(hipEventRecord(E[5], c->side));
-        HIP_TRY(launch_spots(cands1, counts1, st1, n1, mc, p.min_score, d_dec + lo * kMaxMessages, d_nres + lo, c->stream));
-        t.mark(8);
-    }
+    // side stream: spots(A) while decode(B) runs
+    HIP_TRY(hipStreamWaitEvent(c->side, E[4], 0));
+    t.mark_side(4);
+    HIP_TRY(launch_spots(c->d_cands, c->d_counts, c->d_status, n0, mc, p.min_score, d_dec, d_nres, c->side));
+    t.mark_side(5);
+    HIP_TRY(hipEventRecord(E[5], c->side));
+    HIP_TRY(launch_spots(cands1, counts1, st1, n1, mc, p.min_score, d_dec + lo * kMaxMessages, d_nres + lo, c->stream));
+    t.mark(7);
     HIP_TRY(hipStreamWaitEvent(c->stream, E[5], 0));
-    t.mark(9);
-    t.done(two_streams ? 2 : 1);
+    t.mark(8);
+    t.done(1);
     return 0;
 }
 
@@ -449,21 +441,14 @@ int ft8gpu_get_timings(ft8gpu_ctx *c, ft8gpu_timings *out, int32_t *nruns) {
         hipEvent_t *e = c->ev[slot];
         if (c->slot_form[slot] != 0) {
             hipEvent_t *sd = e + ft8gpu_ctx::kSideEv0;
-            HIP_TRY(hipEventSynchronize(e[9]));
+            HIP_TRY(hipEventSynchronize(e[8]));
             HIP_TRY(hipEventSynchronize(sd[5]));
-            acc[0] += elapsed(e[0], e[1]) + elapsed(e[2], e[3]);             // waterfall: both halves
-            acc[1] += elapsed(e[1], e[2]) + elapsed(e[3], e[4]);             // sync: both halves
-            acc[2] += elapsed(sd[0], sd[1]) + elapsed(sd[2], sd[3]);         // heap: both halves (side stream, overlapped)
-            if (c->slot_form[slot] == 1) {
-                acc[3] += elapsed(e[5], e[6]) + elapsed(e[6], e[7]);         // decode: both launches, back to back on the main stream
-                acc[4] += elapsed(sd[4], sd[5]) + elapsed(e[7], e[8]);       // spots: H0 (side, overlapped) + H1
-            } else {
-                // two LDPC kernels in flight on two streams: the stage's duration is the span from the first start to the last end
-                const float main_end = elapsed(e[5], e[6]), side_end = elapsed(e[5], sd[5]);
-                acc[3] += main_end > side_end ? main_end : side_end;
-                acc[4] += elapsed(e[7], e[8]);                               // spots(H0); spots(H1) is inside the side span
-            }
-            acc[5] += elapsed(e[0], e[9]);
+            acc[0] += elapsed(e[0], e[1]);                                   // waterfall
+            acc[1] += elapsed(e[1], e[2]) + elapsed(e[2], e[3]);             // sync: both parts
+            acc[2] += elapsed(sd[0], sd[1]) + elapsed(sd[2], sd[3]);         // heap: both parts (side stream, overlapped)
+            acc[3] += elapsed(e[4], e[5]) + elapsed(e[5], e[6]);             // decode: both launches
+            acc[4] += elapsed(sd[4], sd[5]) + elapsed(e[6], e[7]);           // spots: A (side, overlapped) + B
+            acc[5] += elapsed(e[0], e[8]);
             launches = 2;
         } else {
             HIP_TRY(hipEventSynchronize(e[5]));

@@ -148,7 +148,6 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
     __shared__ __attribute__((aligned(16))) float2 s_in[kWfSpan];            // staged samples, (I, Q) interleaved
     __shared__ __attribute__((aligned(16))) float2 s_x[4][kXbuf];            // per-wave exchange
     __shared__ __attribute__((aligned(16))) float s_thr[260];
-    __shared__ __attribute__((aligned(16))) unsigned char s_out[4][512];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: keep it in an SGPR
@@ -178,7 +177,10 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
     }
 
     float2 *xb = s_x[wave];
-    unsigned char *ob = s_out[wave];
+    // the 512 output bytes of a row are staged at the front of the wave's exchange buffer: by then every lane has
+    // issued its stage-4 reads, and a wave's LDS operations execute in order.  (Keeping the workgroup at 50 KB
+    // leaves room for a heap-replay workgroup of the other half-batch beside three resident workgroups per CU.)
+    unsigned char *ob = reinterpret_cast<unsigned char *>(xb);
     // second exchange: this lane writes elements 64*b16 + j2 + 4a (c = 16*b16 + a, e = j2) and reads butterflies lane + 64 i
     int wbase2[4];
 #pragma unroll
