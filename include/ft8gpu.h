@@ -126,9 +126,6 @@ int  ft8gpu_set_stream(ft8gpu_ctx *ctx, void *hip_stream);
 #define FT8GPU_DBG_PIPELINE_FORM  2u  /* ft8gpu_decode_candidates runs the form of the LDPC kernel ft8gpu_decode_batch
                                          uses (no exact error count: ldpc_errors is 0 or 83) */
 #define FT8GPU_DBG_NO_OVERLAP     4u  /* one launch per stage for the whole batch: no two-half overlap, no chunked upload */
-#define FT8GPU_DBG_SYNC_OLD       8u  /* the first form of the sync kernel (kept for A/B measurements of the second) */
-/* bits 8..11: size of the first part of an overlapped batch in sixteenths of the batch (0 = default 2) */
-#define FT8GPU_DBG_WF_OLD         32u  /* waterfall kernel with the first (bank-conflicting) layout of its second exchange (A/B) */
 int  ft8gpu_set_debug_flags(ft8gpu_ctx *ctx, unsigned flags);
 int  ft8gpu_set_params(ft8gpu_ctx *ctx, const ft8gpu_params *params);
 int  ft8gpu_enable_timing(ft8gpu_ctx *ctx, int on);

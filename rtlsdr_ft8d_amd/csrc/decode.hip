@@ -46,14 +46,18 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // that are tested on the scalar unit against the ballot words; only a word that passes all of them
 // (every codeword does; a non-codeword with e failed rows does so with probability ~2^-(groups-1)
 // when e is even and never when e is odd) goes through the exact per-row check on the vector unit.
-constexpr int kCheckGroups = 4;
+// The number of masks is a template parameter of the kernel: 3 keeps the kernel at 78 SGPRs, and 256-thread
+// workgroups are admitted 8 per CU only up to 80 (MI355X_MICROARCH.md, residency); 4 masks (84 SGPRs, 7
+// workgroups per CU) screen twice as well but hold one wave per SIMD less.  Measured in one session: 5.000 ms
+// against 5.002 ms per 4096-frame batch -- the kernel is bound by VALU issue either way; 3 is kept.
+constexpr int kMaxCheckGroups = 4;
 
 struct DecodeTables {
     uint16_t edge_slot[3][64][3];     // [r][lane][m_idx] -> float index of slot (m, pos) in the LDS tile
     uint64_t rowmask[2][64][3];       // [rr][lane][word] bit mask of the variables of check m = lane + 64 rr
     uint8_t  row_valid[2][64];
     uint8_t  row_seven[2][64];        // row has 7 members (else 6: slot 6 must stay 1.0f)
-    uint64_t group_mask[kCheckGroups][3];   // XOR of the row masks of check rows m with m % kCheckGroups == g
+    uint64_t group_mask[kMaxCheckGroups + 1][kMaxCheckGroups][3];   // [G][g]: XOR of the row masks of check rows m with m % G == g
 };
 
 __device__ DecodeTables d_tab;
@@ -208,7 +212,7 @@ __device__ inline uint32_t crc14_82(const uint8_t *msg) {
 // which consumes only ok / crc / text) the exact check runs only on words that pass the scalar group
 // test, and ldpc_errors is 0 for a codeword and 83 otherwise; the exit iteration and every other field
 // are the same in both forms.
-template <bool COUNT_ERRORS>
+template <bool COUNT_ERRORS, int kCheckGroups>
 __global__ __launch_bounds__(256)
 void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *__restrict__ cands,
                        const int32_t *__restrict__ counts, ft8gpu_decode_status *__restrict__ status,
@@ -292,7 +296,7 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
 #pragma unroll
         for (int g = 0; g < kCheckGroups; ++g)
 #pragma unroll
-            for (int w = 0; w < 3; ++w) gmask[g][w] = d_tab.group_mask[g][w];      // wave-uniform: scalar loads
+            for (int w = 0; w < 3; ++w) gmask[g][w] = d_tab.group_mask[kCheckGroups][g][w];      // wave-uniform: scalar loads
     }
     uint64_t rmask[2][3];
     bool rvalid[2], rseven[2];
@@ -590,13 +594,15 @@ hipError_t decode_tables_init(hipStream_t s) {
                 h.rowmask[rr][l][n >> 6] |= 1ull << (n & 63);
             }
         }
-    for (int g = 0; g < kCheckGroups; ++g)
-        for (int w = 0; w < 3; ++w) h.group_mask[g][w] = 0;
-    for (int m = 0; m < kLdpcM; ++m)
-        for (int j = 0; j < kFT8_Num_rows[m]; ++j) {
-            const int n = kFT8_Nm[m][j] - 1;
-            h.group_mask[m % kCheckGroups][n >> 6] ^= 1ull << (n & 63);
-        }
+    for (int G = 1; G <= kMaxCheckGroups; ++G) {
+        for (int g = 0; g < kMaxCheckGroups; ++g)
+            for (int w = 0; w < 3; ++w) h.group_mask[G][g][w] = 0;
+        for (int m = 0; m < kLdpcM; ++m)
+            for (int j = 0; j < kFT8_Num_rows[m]; ++j) {
+                const int n = kFT8_Nm[m][j] - 1;
+                h.group_mask[G][m % G][n >> 6] ^= 1ull << (n & 63);
+            }
+    }
     return hipMemcpyToSymbolAsync(HIP_SYMBOL(d_tab), &h, sizeof(h), 0, hipMemcpyHostToDevice, s);
 }
 
@@ -611,10 +617,10 @@ hipError_t launch_decode(const uint8_t *mag, const ft8gpu_candidate *cands, cons
     if (nblocks * bpf >= (1ull << 32)) return hipErrorInvalidValue;           // keeps the multiply-high division exact
     const unsigned magic = (unsigned)((1ull << 32) / bpf) + 1u;
     if (count_errors)
-        hipLaunchKernelGGL(ft8_decode_kernel<true>, dim3((unsigned)nblocks), dim3(256), 0, s,
+        hipLaunchKernelGGL((ft8_decode_kernel<true, 1>), dim3((unsigned)nblocks), dim3(256), 0, s,
                            mag, cands, counts, status, nframes, max_candidates, ldpc_iters, force_ieee_div, bpf, magic);
     else
-        hipLaunchKernelGGL(ft8_decode_kernel<false>, dim3((unsigned)nblocks), dim3(256), 0, s,
+        hipLaunchKernelGGL((ft8_decode_kernel<false, 3>), dim3((unsigned)nblocks), dim3(256), 0, s,
                            mag, cands, counts, status, nframes, max_candidates, ldpc_iters, force_ieee_div, bpf, magic);
     return hipGetLastError();
 }

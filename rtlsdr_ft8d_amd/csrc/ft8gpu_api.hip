@@ -178,7 +178,6 @@ struct StageTimer {
     }
 };
 
-inline int sync_old(const ft8gpu_ctx *c) { return (c->debug_flags & FT8GPU_DBG_SYNC_OLD) ? 1 : 0; }
 inline int force_ieee(const ft8gpu_ctx *c) { return (c->debug_flags & FT8GPU_DBG_FORCE_IEEE_DIV) ? 1 : 0; }
 
 float elapsed(hipEvent_t a, hipEvent_t b) {
@@ -200,9 +199,9 @@ int run_pipeline_overlapped(ft8gpu_ctx *c, const float *d_iq, int n, struct deco
     StageTimer t(c);
     const ft8gpu_params &p = c->params;
     const int mc = p.max_candidates;
-    // size of part A in 1/16ths of the batch (debug knob in flag bits 8..11), whole blocks of 64 frames.  Swept at 4096
-    // frames in one session: 1/16 4.99 ms, 2/16 5.03, 4/16 5.03, 8/16 5.22; one launch per stage 5.14.
-    const int sixteenths = ((c->debug_flags >> 8) & 15) ? (int)((c->debug_flags >> 8) & 15) : (n >= 2048 ? 1 : 2);
+    // size of part A in 1/16ths of the batch, whole blocks of 64 frames.  Swept at 4096 frames in one session
+    // (profiles/r02_ab_kernels.json): 1/16 4.99 ms, 2/16 5.03, 4/16 5.03, 8/16 5.22; one launch per stage 5.14.
+    const int sixteenths = n >= 2048 ? 1 : 2;
     int n0 = ((n * sixteenths / 16) + 63) & ~63;
     if (n0 < 64) n0 = 64;
     if (n0 > n - 64) n0 = n / 2;
@@ -214,18 +213,17 @@ int run_pipeline_overlapped(ft8gpu_ctx *c, const float *d_iq, int n, struct deco
     ft8gpu_candidate *cands1 = c->d_cands + lo * mc;
     int32_t *counts1 = c->d_counts + lo;
     ft8gpu_decode_status *st1 = c->d_status + lo * mc;
-    const int wf_old = (c->debug_flags & FT8GPU_DBG_WF_OLD) ? 1 : 0;
     hipEvent_t *E = c->dep;          // 0: sync(A) done  1: sync(B) done  2: heap(A)  3: heap(B)  4: decode(A)  5: side stream done
 
     // main stream events: 0 waterfall 1 sync(A) 2 sync(B) 3 | 4 decode(A) 5 decode(B) 6 spots(B) 7 | 8 end
     // side stream events: 0 heap(A) 1 | 2 heap(B) 3 | 4 spots(A) 5
     t.mark(0);
-    HIP_TRY(launch_waterfall(d_iq, c->d_mag, c->d_tab, n, c->num_cus, wf_old, c->stream));
+    HIP_TRY(launch_waterfall(d_iq, c->d_mag, c->d_tab, n, c->num_cus, c->stream));
     t.mark(1);
-    HIP_TRY(launch_sync(c->d_mag, c->d_lists, c->d_list_counts, nullptr, n0, p.min_score, sync_old(c), c->stream));
+    HIP_TRY(launch_sync(c->d_mag, c->d_lists, c->d_list_counts, nullptr, n0, p.min_score, c->stream));
     HIP_TRY(hipEventRecord(E[0], c->stream));
     t.mark(2);
-    HIP_TRY(launch_sync(mag1, lists1, lc1, nullptr, n1, p.min_score, sync_old(c), c->stream));
+    HIP_TRY(launch_sync(mag1, lists1, lc1, nullptr, n1, p.min_score, c->stream));
     HIP_TRY(hipEventRecord(E[1], c->stream));
     t.mark(3);
     // side stream: heap(A), heap(B)
@@ -268,9 +266,9 @@ int run_pipeline(ft8gpu_ctx *c, const float *d_iq, int n, struct decoder_results
     StageTimer t(c);
     const ft8gpu_params &p = c->params;
     t.mark(0);
-    HIP_TRY(launch_waterfall(d_iq, c->d_mag, c->d_tab, n, c->num_cus, (c->debug_flags & FT8GPU_DBG_WF_OLD) ? 1 : 0, c->stream));
+    HIP_TRY(launch_waterfall(d_iq, c->d_mag, c->d_tab, n, c->num_cus, c->stream));
     t.mark(1);
-    HIP_TRY(launch_sync(c->d_mag, c->d_lists, c->d_list_counts, nullptr, n, p.min_score, sync_old(c), c->stream));
+    HIP_TRY(launch_sync(c->d_mag, c->d_lists, c->d_list_counts, nullptr, n, p.min_score, c->stream));
     t.mark(2);
     HIP_TRY(launch_heap(c->d_lists, c->d_list_counts, c->d_cands, c->d_counts, n, p.max_candidates, c->stream));
     t.mark(3);
@@ -629,11 +627,11 @@ int ft8gpu_waterfall(ft8gpu_ctx *c, const float *iq, int nframes, uint8_t *mag, 
     for (int f0 = 0; f0 < nframes; f0 += c->max_frames) {
         const int n = (nframes - f0 < c->max_frames) ? nframes - f0 : c->max_frames;
         if (flags & FT8GPU_DEVICE_PTRS) {
-            HIP_TRY(launch_waterfall(iq + f0 * frame_floats, mag + (size_t)f0 * kMagArray, c->d_tab, n, c->num_cus, (c->debug_flags & FT8GPU_DBG_WF_OLD) ? 1 : 0, c->stream));
+            HIP_TRY(launch_waterfall(iq + f0 * frame_floats, mag + (size_t)f0 * kMagArray, c->d_tab, n, c->num_cus, c->stream));
         } else {
             if (!c->d_iq) HIP_TRY(hipMalloc(&c->d_iq, (size_t)c->max_frames * frame_floats * sizeof(float)));
             HIP_TRY(hipMemcpyAsync(c->d_iq, iq + f0 * frame_floats, n * frame_floats * sizeof(float), hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(launch_waterfall(c->d_iq, c->d_mag, c->d_tab, n, c->num_cus, (c->debug_flags & FT8GPU_DBG_WF_OLD) ? 1 : 0, c->stream));
+            HIP_TRY(launch_waterfall(c->d_iq, c->d_mag, c->d_tab, n, c->num_cus, c->stream));
             HIP_TRY(hipMemcpyAsync(mag + (size_t)f0 * kMagArray, c->d_mag, (size_t)n * kMagArray, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
         }
@@ -653,7 +651,7 @@ int ft8gpu_find_sync(ft8gpu_ctx *c, const uint8_t *mag, int nframes, ft8gpu_cand
         ft8gpu_candidate *dc = dev ? cands + (size_t)f0 * mc : c->d_cands;
         int32_t *dn = dev ? counts + f0 : c->d_counts;
         if (!dev) HIP_TRY(hipMemcpyAsync(c->d_mag, mag + (size_t)f0 * kMagArray, (size_t)n * kMagArray, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(launch_sync(dm, c->d_lists, c->d_list_counts, nullptr, n, c->params.min_score, sync_old(c), c->stream));
+        HIP_TRY(launch_sync(dm, c->d_lists, c->d_list_counts, nullptr, n, c->params.min_score, c->stream));
         HIP_TRY(launch_heap(c->d_lists, c->d_list_counts, dc, dn, n, mc, c->stream));
         if (!dev) {
             HIP_TRY(hipMemcpyAsync(cands + (size_t)f0 * mc, dc, (size_t)n * mc * sizeof(ft8gpu_candidate), hipMemcpyDeviceToHost, c->stream));
@@ -675,7 +673,7 @@ int ft8gpu_score_map(ft8gpu_ctx *c, const uint8_t *mag, int nframes, int16_t *sc
         const uint8_t *dm = dev ? mag + (size_t)f0 * kMagArray : c->d_mag;
         int16_t *ds = dev ? scores + (size_t)f0 * kScoresPerFrame : c->d_scores;
         if (!dev) HIP_TRY(hipMemcpyAsync(c->d_mag, mag + (size_t)f0 * kMagArray, (size_t)n * kMagArray, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(launch_sync(dm, c->d_lists, c->d_list_counts, ds, n, c->params.min_score, sync_old(c), c->stream));
+        HIP_TRY(launch_sync(dm, c->d_lists, c->d_list_counts, ds, n, c->params.min_score, c->stream));
         if (!dev) {
             HIP_TRY(hipMemcpyAsync(scores + (size_t)f0 * kScoresPerFrame, ds, (size_t)n * kScoresPerFrame * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));

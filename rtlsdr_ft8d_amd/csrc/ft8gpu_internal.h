@@ -39,9 +39,9 @@ struct Ft8Tables {                 // device-resident constant tables, built on 
 
 // kernel launchers (each enqueues on `s`, returns hipGetLastError())
 hipError_t launch_waterfall(const float *iq, uint8_t *mag, const Ft8Tables *tab, int nframes,
-                            int num_cus, int old_layout, hipStream_t s);
+                            int num_cus, hipStream_t s);
 hipError_t launch_sync(const uint8_t *mag, uint32_t *lists, int32_t *list_counts, int16_t *score_map,
-                       int nframes, int min_score, int old_form, hipStream_t s);
+                       int nframes, int min_score, hipStream_t s);
 hipError_t launch_heap(const uint32_t *lists, const int32_t *list_counts, ft8gpu_candidate *cands,
                        int32_t *counts, int nframes, int max_candidates, hipStream_t s);
 hipError_t launch_decode(const uint8_t *mag, const ft8gpu_candidate *cands, const int32_t *counts,

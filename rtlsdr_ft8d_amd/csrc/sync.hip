@@ -6,9 +6,11 @@
 //                    Costas blocks m and seven symbols k, neighbour contrasts of the waterfall at block
 //                    b = t0 + 36 m + k.  Which terms exist depends on b and k only, never on the
 //                    frequency, so the sum over m is taken ONCE per (t0 + k) while the slice streams
-//                    through registers ("collapsed maps" in LDS), and a position's score is seven int16
-//                    reads and six adds.  Positions with score >= min_score are compacted in the
-//                    reference's scan order with __ballot/popcount prefix sums (no atomics).
+//                    through registers ("collapsed maps" in LDS), and a position's score numerator is the
+//                    sum of seven map cells.  A lane scores four adjacent frequency offsets at once with
+//                    packed int16 adds; whether trunc(numerator / terms) reaches min_score is decided
+//                    exactly on the numerator, and only surviving positions get their quotient.  Survivors
+//                    are compacted in the reference's scan order with __ballot/popcount prefix sums (no atomics).
 //   ft8_heap_kernel  replays the reference's bounded min-heap (strict '>' replacement, its
 //                    heapify tie rules and the final heap sort) over the compacted list, one
 //                    wave per frame with the heap in LDS, so that candidate order is bit-identical
@@ -32,7 +34,6 @@ constexpr int kMapPitch = 256;                            // int16 per map row
 constexpr int kRowsA = 40, kRowsK = 36;                   // rows of MA / of M0, M3, M6
 constexpr int kOffA = 0, kOff0 = kRowsA, kOff3 = kRowsA + kRowsK, kOff6 = kRowsA + 2 * kRowsK;
 constexpr int kMapRows = kRowsA + 3 * kRowsK;             // 148 rows
-constexpr int kSyncLds = kMapRows * kMapPitch * 2;        // 75776 bytes: two workgroups per CU
 constexpr int kTqCount = 42;                              // t' = tq - 12 for tq in [0, 42)
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -59,128 +60,7 @@ __device__ __forceinline__ int sync_navg(int t0) {
     return n;
 }
 
-__global__ __launch_bounds__(64 * kSyncWaves)
-void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lists,
-                     int32_t *__restrict__ list_counts, int16_t *__restrict__ score_map, int min_score) {
-    __shared__ __attribute__((aligned(16))) int16_t s_map[kMapRows * kMapPitch];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: keep it in an SGPR
-    const int frame = blockIdx.x >> 2, seg = blockIdx.x & 3;
-    const int ts = seg >> 1, fs = seg & 1;
-
-    // ---- build the collapsed maps ------------------------------------------------------------------
-    // mag[block][time_sub][freq_sub][bin]: one 256-byte run per block for this (ts, fs); lane = column
-    // group (4 bins).  A wave owns consecutive t' and slides a three-row window (b-1, b, b+1) per Costas
-    // block m down the slice, so every row is fetched once per wave that needs it, straight from global
-    // memory / L2 (the slice never sits in LDS).
-    {
-        const uint32_t *rows = reinterpret_cast<const uint32_t *>(mag + (size_t)frame * kMagArray + ts * 512 + fs * 256) + lane;
-        auto fetch = [&](int b) -> uint32_t {           // b is wave-uniform
-            return (b >= 0 && b < kNumBlocks) ? rows[(size_t)b * (kBlockStride / 4)] : 0u;
-        };
-        const int tq_begin = (wave * kTqCount) / kSyncWaves, tq_end = ((wave + 1) * kTqCount) / kSyncWaves;
-        uint32_t prev[3], cur[3], next[3];
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            prev[m] = fetch(tq_begin - 12 + 36 * m - 1);
-            cur[m] = fetch(tq_begin - 12 + 36 * m);
-        }
-        for (int tq = tq_begin; tq < tq_end; ++tq) {
-            const int tp = tq - 12;                     // t'
-#pragma unroll
-            for (int m = 0; m < 3; ++m) next[m] = fetch(tp + 36 * m + 1);
-            // Sums of the centre bytes and of each neighbour over the valid m; the differences are formed
-            // once per cell afterwards (sum(c - x) = sum(c) - sum(x)); |sums| <= 3 * 255.
-            s16x2 C[2] = { { 0, 0 }, { 0, 0 } }, L[2] = { { 0, 0 }, { 0, 0 } }, R[2] = { { 0, 0 }, { 0, 0 } };
-            s16x2 Up[2] = { { 0, 0 }, { 0, 0 } }, Dn[2] = { { 0, 0 }, { 0, 0 } };
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                const int b = tp + 36 * m;
-                if (b < 0 || b >= kNumBlocks) continue;                       // wave-uniform
-                const uint32_t mid = cur[m];
-                const uint32_t up = b > 0 ? prev[m] : mid;                    // missing time neighbour: p - p = 0
-                const uint32_t dn = b + 1 < kNumBlocks ? next[m] : mid;
-                // neighbouring column groups: whole-wave DPP shifts (one VALU move each, no LDS crossbar trip)
-                const uint32_t lnb = (uint32_t)__builtin_amdgcn_update_dpp((int)mid, (int)mid, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-                const uint32_t rnb = (uint32_t)__builtin_amdgcn_update_dpp((int)mid, (int)mid, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
-                const uint32_t left = lane > 0 ? lnb >> 24 : mid & 0xFFu;     // column 0 has no lower bin: p - p = 0
-                const uint32_t right = lane < 63 ? rnb & 0xFFu : 0u;          // column 255 is never addressed (f0 + tone <= 254)
-                const s16x2 m12 = bytes2(0, mid, 0x0c020c01u);                // (m1, m2): right of (m0, m1), left of (m2, m3)
-                C[0] += bytes2(0, mid, 0x0c010c00u);   C[1] += bytes2(0, mid, 0x0c030c02u);
-                L[0] += bytes2(left, mid, 0x0c000c04u); L[1] += m12;          // (left, m0), (m1, m2)
-                R[0] += m12;                            R[1] += bytes2(right, mid, 0x0c040c03u);   // (m1, m2), (m3, right)
-                Up[0] += bytes2(0, up, 0x0c010c00u);   Up[1] += bytes2(0, up, 0x0c030c02u);
-                Dn[0] += bytes2(0, dn, 0x0c010c00u);   Dn[1] += bytes2(0, dn, 0x0c030c02u);
-            }
-            s16x2 S[2], U[2], V[2], W[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                W[h] = C[h] - L[h];                                           // sum of dl
-                U[h] = C[h] - Up[h];                                          // sum of du
-                V[h] = C[h] - Dn[h];                                          // sum of dd
-                S[h] = (W[h] + (C[h] - R[h])) + (U[h] + V[h]);                // sum of dl + dr + du + dd
-            }
-            auto store = [&](int row, s16x2 a, s16x2 b2) {
-                uint2 v;
-                v.x = __builtin_bit_cast(uint32_t, a);
-                v.y = __builtin_bit_cast(uint32_t, b2);
-                *reinterpret_cast<uint2 *>(s_map + row * kMapPitch + 4 * lane) = v;
-            };
-            if (tp >= -11 && tp < 29) store(kOffA + tp + 11, S[0], S[1]);
-            if (tp >= -12 && tp < 24) store(kOff0 + tp + 12, S[0] - U[0], S[1] - U[1]);
-            if (tp >= -9 && tp < 27)  store(kOff3 + tp + 9, S[0] - W[0], S[1] - W[1]);
-            if (tp >= -6 && tp < 30)  store(kOff6 + tp + 6, S[0] - V[0], S[1] - V[1]);
-#pragma unroll
-            for (int m = 0; m < 3; ++m) { prev[m] = cur[m]; cur[m] = next[m]; }
-        }
-    }
-    __syncthreads();
-
-    // ---- score all positions -----------------------------------------------------------------------
-    const int sub = seg * kSyncWaves + wave;
-    uint32_t *my_list = lists + ((size_t)frame * kSublistsPerFrame + sub) * kSublistCap;
-    int count = 0;
-    const int t_begin = (wave * kT0Count) / kSyncWaves, t_end = ((wave + 1) * kT0Count) / kSyncWaves;
-
-    for (int t0i = t_begin; t0i < t_end; ++t0i) {        // scan order: time_offset ascending
-        const int t0 = t0i + kT0Min;
-        const int navg = sync_navg(t0);
-        // score /= navg (C int division, truncating toward zero) without an integer divide: with
-        // |score| <= 21*4*255 and navg <= 84 the quotient is either an integer or at least 1/84 away from
-        // one, while float(score)*fl(1/navg) is within 2e-3 of it, so adding 0.004 away from zero and
-        // truncating is exact.
-        const float rnavg = navg > 0 ? 1.0f / (float)navg : 1.0f;
-        // row t0i of M0 / M3 / M6 is t' = t0 / t0 + 3 / t0 + 6; row t0i + k - 1 of MA is t' = t0 + k
-        const int16_t *ma = s_map + (kOffA + t0i) * kMapPitch;
-        const int16_t *m0 = s_map + (kOff0 + t0i) * kMapPitch, *m3 = s_map + (kOff3 + t0i) * kMapPitch, *m6 = s_map + (kOff6 + t0i) * kMapPitch;
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int f0 = pass * 64 + lane;            // then freq_offset ascending
-            const bool valid = f0 < kF0Count;
-            const int fc = valid ? f0 : 0;
-            int score = ((int)m0[fc + 3] + (int)ma[0 * kMapPitch + fc + 1] + (int)ma[1 * kMapPitch + fc + 4]) +
-                        ((int)m3[fc] + (int)ma[3 * kMapPitch + fc + 6] + (int)ma[4 * kMapPitch + fc + 5]) + (int)m6[fc + 2];
-            {
-                const float fs_ = (float)score;
-                score = (int)(fs_ * rnavg + __builtin_copysignf(0.004f, fs_));
-            }
-            if (valid && score_map)
-                score_map[(size_t)frame * kScoresPerFrame + (seg * kT0Count + t0i) * kF0Count + f0] = (int16_t)score;
-            const bool keep = valid && score >= min_score;
-            const unsigned long long mask = __ballot(keep);
-            if (keep) {
-                const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
-                my_list[pos] = ((uint32_t)(score & 0xFFFF) << 16) | ((uint32_t)t0i << 8) | (uint32_t)f0;
-            }
-            count += __popcll(mask);
-        }
-    }
-    if (lane == 0) list_counts[(size_t)frame * kSublistsPerFrame + sub] = count;
-}
-
-// ---- second form of the sync kernel ----------------------------------------------------------------
-// Same maps, same results, fewer instructions and one memory latency instead of six:
+// ---- the sync kernel -----------------------------------------------------------------------------------
 //   * build: every row a wave needs (its 5-6 consecutive t' plus one halo row either side, for the three
 //     Costas blocks: 24 dwords per lane) is requested up front; each row is widened to int16 once and slides
 //     through a (previous, current, next) window; the horizontal neighbours are taken from the SUM over the
@@ -203,7 +83,7 @@ __device__ __forceinline__ u32 funnel16(u32 hi, u32 lo) { return __builtin_amdgc
 
 template <bool SCORE_MAP>
 __global__ __launch_bounds__(64 * kSyncWaves)
-void ft8_sync_kernel_v2(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lists,
+void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lists,
                         int32_t *__restrict__ list_counts, int16_t *__restrict__ score_map, int min_score) {
     __shared__ __attribute__((aligned(16))) int16_t s_map[kMapRows * kMapPitch + 16];   // + the two dwords lane 63 reads past a row
     __shared__ int s_navg[kT0Count];                             // terms averaged by ft8_sync_score() per time offset
@@ -634,16 +514,13 @@ void ft8_heap_kernel(const uint32_t *__restrict__ lists, const int32_t *__restri
 }  // namespace
 
 hipError_t launch_sync(const uint8_t *mag, uint32_t *lists, int32_t *list_counts, int16_t *score_map,
-                       int nframes, int min_score, int old_form, hipStream_t s) {
+                       int nframes, int min_score, hipStream_t s) {
     if (nframes < 1) return hipSuccess;
-    if (old_form)
-        hipLaunchKernelGGL(ft8_sync_kernel, dim3(nframes * kSegments), dim3(64 * kSyncWaves), 0, s,
-                           mag, lists, list_counts, score_map, min_score);
-    else if (score_map)
-        hipLaunchKernelGGL(ft8_sync_kernel_v2<true>, dim3(nframes * kSegments), dim3(64 * kSyncWaves), 0, s,
+    if (score_map)
+        hipLaunchKernelGGL(ft8_sync_kernel<true>, dim3(nframes * kSegments), dim3(64 * kSyncWaves), 0, s,
                            mag, lists, list_counts, score_map, min_score);
     else
-        hipLaunchKernelGGL(ft8_sync_kernel_v2<false>, dim3(nframes * kSegments), dim3(64 * kSyncWaves), 0, s,
+        hipLaunchKernelGGL(ft8_sync_kernel<false>, dim3(nframes * kSegments), dim3(64 * kSyncWaves), 0, s,
                            mag, lists, list_counts, score_map, min_score);
     return hipGetLastError();
 }

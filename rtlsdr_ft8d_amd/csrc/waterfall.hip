@@ -141,7 +141,6 @@ __device__ __forceinline__ const float4 *item_vec(const float *__restrict__ iq, 
     return reinterpret_cast<const float4 *>(base + plane * kNSamples) + i;
 }
 
-template <bool OLD_LAYOUT>
 __global__ __launch_bounds__(256)
 void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ mag,
                           const Ft8Tables *__restrict__ tab, int nitems, int nframes, int xcd_order) {
@@ -251,16 +250,15 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
             }
             pass16(x, twA2, twB2);              // stages 2, 3
 #pragma unroll
-            for (int a = 0; a < 16; ++a)
-                xb[OLD_LAYOUT ? pad_idx(64 * b16 + j2 + 4 * a) : wbase2[a & 3] + 8 * (a >> 2)] = make_float2(x[a].x, x[a].y);
+            for (int a = 0; a < 16; ++a) xb[wbase2[a & 3] + 8 * (a >> 2)] = make_float2(x[a].x, x[a].y);
             wave_lds_sync();
 
             // stage 4 (L = 4, no twiddles): butterfly c = lane + 64*i holds bins k0+i (y0) and 256+k0+i (y1)
             unsigned q0[4], q1[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float4 *src = reinterpret_cast<const float4 *>(xb + (OLD_LAYOUT ? pad_idx(4 * (lane + 64 * i)) : rbase2 + 128 * i));   // butterfly c = lane + 64 i
-                const float4 v01 = src[0], v23 = src[OLD_LAYOUT ? 1 : kHalfUnits];
+                const float4 *src = reinterpret_cast<const float4 *>(xb + rbase2 + 128 * i);      // butterfly c = lane + 64 i
+                const float4 v01 = src[0], v23 = src[kHalfUnits];
                 const c32 a0 = { v01.x, v01.y }, a1 = { v01.z, v01.w }, a2 = { v23.x, v23.y }, a3 = { v23.z, v23.w };
                 const c32 t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = a1 - a3;
                 const c32 y0 = t0 + t2;
@@ -288,14 +286,13 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
 }  // namespace
 
 hipError_t launch_waterfall(const float *iq, uint8_t *mag, const Ft8Tables *tab, int nframes,
-                            int num_cus, int old_layout, hipStream_t s) {
+                            int num_cus, hipStream_t s) {
     const int nitems = nframes * kWfItemsPerFrame;
     int grid = num_cus * kWfGridPerCu;           // workgroups per CU (LDS-limited), persistent
     if (grid > nitems) grid = nitems;
     if (grid < 1) return hipSuccess;
     // XCD-aware order needs whole groups of 8 workgroups and enough frames to give every XCD work
     const int xcd_order = (grid % 8 == 0 && nframes >= 64) ? 1 : 0;
-    if (old_layout) hipLaunchKernelGGL(ft8_waterfall_kernel<true>, dim3(grid), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xcd_order);
-    else hipLaunchKernelGGL(ft8_waterfall_kernel<false>, dim3(grid), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xcd_order);
+    hipLaunchKernelGGL(ft8_waterfall_kernel, dim3(grid), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xcd_order);
     return hipGetLastError();
 }
