@@ -33,7 +33,7 @@ def csrc_hash():
 KERNELS = ("ft8_decode_kernel", "ft8_waterfall_kernel", "ft8_sync_kernel", "ft8_heap_kernel", "ft8_spots_kernel",
            "ft8_synth_kernel", "ft8_rx_block_kernel")
 WIDE = {"waterfall", "sync", "rx_block"}
-HALF_BATCH = {"waterfall", "sync", "heap", "decode", "spots"}      # launched once per half batch when the pipeline overlaps halves
+HALF_BATCH = {"sync", "heap", "decode", "spots"}      # two launches per batch (a small first part and the rest): the mean per launch covers half a batch
 
 
 def short(name):
