@@ -101,7 +101,8 @@ def test_score_map_exact(oracle, gpu_decoder, oracle_mags):
         assert np.array_equal(s[k], ref), f"frame {k}: {np.count_nonzero(s[k] != ref)} scores differ"
 
 
-@pytest.mark.parametrize("max_candidates,min_score", [(120, 10), (8, 10), (33, 5), (480, 10), (120, 0), (1000, -5)])
+@pytest.mark.parametrize("max_candidates,min_score", [(120, 10), (8, 10), (33, 5), (480, 10), (120, 0), (1000, -5), (120, 1), (60, 40),
+                                                      (120, 300), (120, 32767), (64, -32768)])   # incl. thresholds beyond any numerator
 def test_find_sync_exact(oracle, gpu_decoder, oracle_mags, max_candidates, min_score):
     gpu_decoder.set_params(min_score=min_score, max_candidates=max_candidates, ldpc_iters=20)
     try:
