@@ -13,8 +13,8 @@
 //   * window and all twiddle factors live in registers for the lifetime of the wave.
 //   * the dB quantiser is evaluated against a 256-entry threshold table derived on the host from
 //     the reference expression itself (host libm log10f), so the uint8 result is bit-identical to
-//     (int)(2*(10.0f*log10f(1e-12f + mag2*4.0f/(NFFT*NFFT)))+240); v_log_f32 only provides the
-//     first guess.
+//     (int)(2*(10.0f*log10f(1e-12f + mag2*4.0f/(NFFT*NFFT)))+240); v_log_f32 only provides a
+//     guess known to be the result or one below it.
 //   * arithmetic order of the FFT is the "R4DIF-1024" order documented in DESIGN.md; compiled with
 //     -ffp-contract=off so every float operation is a single IEEE operation.
 #include "ft8gpu_internal.h"
@@ -99,21 +99,32 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// rtlsdr_ft8d.c:1415-1427 for one bin; qthr[k] = smallest float y with quantised value >= k
-// (qthr[0] = 0, qthr[256] = NaN: never compares true).  v_log_f32 (1 ulp) puts the guess 6.0206*log2(y)+240 within
-// 1e-2 of the reference's float expression, so the truncated guess is off by at most one step and a
-// single comparison against the two neighbouring thresholds makes it exact -- branch-free, with
-// both table reads of all eight bins of a lane in flight together.
-__device__ __forceinline__ unsigned quantise(float re, float im, const float *qthr) {
-    const float mag2 = re * re + im * im;
-    const float y = 1E-12f + (mag2 * 4.0f) / 1048576.0f;
-    int k = (int)(6.0206f * __log2f(y) + 240.0f);
-    k = k < 0 ? 0 : (k > 255 ? 255 : k);
-    const float t0 = qthr[k], t1 = qthr[k + 1];
-    k += (y >= t1 ? 1 : 0) - (y < t0 ? 1 : 0);
-    // (y = +inf, i.e. |X|^2 overflowed: the guess saturates to 255 and qthr[256] is NaN, so k stays 255 --
-    // the fence documented in DESIGN.md; y = NaN: the guess converts to 0 and no comparison holds, k = 0)
-    return (unsigned)k;
+// rtlsdr_ft8d.c:1415-1427 for two bins (y0 and y1 of a stage-4 butterfly); qthr[k] = smallest float y with
+// quantised value >= k (qthr[0] = 0, qthr[256] = NaN: never compares true).
+//   * y = 1e-12f + (mag2 * 4.0f) / 1048576.0f: the product and the division by 2^20 are exact scalings, so one
+//     multiplication by 2^-18 gives the same y whenever neither intermediate leaves the normal range; a
+//     subnormal quotient (< 1.2e-38) vanishes in 1e-12f either way, and where mag2 * 4 overflows to inf the
+//     reference quantises inf (255 by the fence of DESIGN.md) while this y stays finite but far above
+//     qthr[255] -- 255 as well.
+//   * v_log_f32 (1 ulp) puts g = 6.0206 log2(y) + 240 within 1e-4 of the reference's float expression
+//     2 * (10 * log10f(y)) + 240, whose truncation is the result q.  With the guess biased DOWN by 0.01,
+//     kl = trunc(g - 0.01) satisfies kl <= q <= kl + 1, and q = kl + 1 exactly when y >= qthr[kl + 1]: one table
+//     read and one comparison per bin, branch-free.  (y = +inf: the guess saturates, kl = 255, NaN never
+//     compares, 255; y = NaN: the guess converts to 0, the comparison fails, 0.)
+// Written on pairs so that the scalings and the affine map of the logarithm are packed instructions.
+__device__ __forceinline__ void quantise2(c32 a, c32 b, const float *qthr, unsigned &qa, unsigned &qb) {
+    const c32 sa = a * a, sb = b * b;
+    c32 mag2;                           // horizontal adds, written opaquely: the vectoriser otherwise transposes the two pairs with three moves
+    asm("v_add_f32 %0, %1, %2" : "=v"(mag2.x) : "v"(sa.x), "v"(sa.y));
+    asm("v_add_f32 %0, %1, %2" : "=v"(mag2.y) : "v"(sb.x), "v"(sb.y));
+    const c32 y = mag2 * c32{ 0x1p-18f, 0x1p-18f } + c32{ 1E-12f, 1E-12f };
+    const c32 l = { __log2f(y.x), __log2f(y.y) };
+    const c32 g = l * c32{ 6.0206f, 6.0206f } + c32{ 239.99f, 239.99f };
+    int ka = (int)g.x, kb = (int)g.y;
+    ka = ka > 255 ? 255 : ka;
+    kb = kb > 255 ? 255 : kb;
+    qa = (unsigned)ka + (y.x >= qthr[ka + 1] ? 1u : 0u);
+    qb = (unsigned)kb + (y.y >= qthr[kb + 1] ? 1u : 0u);
 }
 
 constexpr int kXbuf = 1088;     // 1024 + 4 per 64 padding, complex entries per wave
@@ -263,8 +274,7 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
                 const c32 t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = a1 - a3;
                 const c32 y0 = t0 + t2;
                 const c32 y1 = add_mul_mi(t1, t3);
-                q0[i] = quantise(y0.x, y0.y, s_thr);
-                q1[i] = quantise(y1.x, y1.y, s_thr);
+                quantise2(y0, y1, s_thr, q0[i], q1[i]);
             }
             // bins k0..k0+3 -> [freq_sub = k&1][pos = k>>1]  (rtlsdr_ft8d.c:1420-1428)
             const int k0 = 64 * (lane & 3) + 16 * ((lane >> 2) & 3) + 4 * (lane >> 4);
