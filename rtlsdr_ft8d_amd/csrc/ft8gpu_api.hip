@@ -200,7 +200,8 @@ int run_pipeline_overlapped(ft8gpu_ctx *c, const float *d_iq, int n, struct deco
     const ft8gpu_params &p = c->params;
     const int mc = p.max_candidates;
     // size of part A in 1/16ths of the batch, whole blocks of 64 frames.  Swept at 4096 frames in one session
-    // (profiles/r02_ab_kernels.json): 1/16 4.99 ms, 2/16 5.03, 4/16 5.03, 8/16 5.22; one launch per stage 5.14.
+    // (profiles/r02_ab_kernels.json): 1/16 4.99 ms, 2/16 5.03, 4/16 5.03, 8/16 5.22; one launch per stage 5.14; a later
+    // sweep in frames (128 ... 768) stayed within 4.978-4.992 ms: the size is not critical as long as it is small.
     const int sixteenths = n >= 2048 ? 1 : 2;
     int n0 = ((n * sixteenths / 16) + 63) & ~63;
     if (n0 < 64) n0 = 64;
