@@ -216,6 +216,16 @@ def test_unpack_all_message_types(oracle, gpu_decoder):
             p[8] = (ig >> 2) & 0xFF
             p[9] = (p[9] & 0x3F) | ((ig & 3) << 6)
         payloads.append(bytes(p))
+    # messages of every kind from the independent encoder (tests/ft8_spec_pack.py, written from the published protocol)
+    import ft8_spec_pack as P
+    payloads += [P.pack_standard("K1ABC", "W9XYZ", x) for x in ("EN37", "R EN37", "-11", "R+07", "RRR", "RR73", "73", "")]
+    payloads += [P.pack_standard("K1ABC/R", "W9XYZ", "EN37", i3=1), P.pack_standard("G4ABC", "PA9XYZ/P", "JO22", i3=2),
+                 P.pack_standard("CQ 123", "DL1ABC", "JO62"), P.pack_standard("CQ DX", "VK3ABC", "QF22"),
+                 P.pack_standard("CQ TEST", "9A1A", "JN75"), P.pack_standard("QRZ", "JA1XYZ", "PM95"), P.pack_standard("DE", "3D2AG", "RH91")]
+    payloads += [P.pack_free_text(t) for t in ("TNX BOB 73 GL", "A", "+-./?0123 ZY", "HELLO WORLD")]
+    payloads += [P.pack_telemetry("0123456789ABCDEF01"), P.pack_telemetry("7FFFFFFFFFFFFFFFFF")]
+    payloads += [P.pack_nonstandard("PJ4/K1ABC", 1234, icq=1), P.pack_nonstandard("YW18FIFA", 77, flip=0, nrpt=2),
+                 P.pack_nonstandard("KH1/KH7Z", 4095, flip=1, nrpt=3), P.pack_nonstandard("W9XYZ/QRP", 0, flip=1, nrpt=0)]
     n = len(payloads)
     # paint each codeword as a clean signal into its own waterfall at time_offset 0 / freq_offset 10
     mags = np.full((n, 92, 2, 2, 256), 60, np.uint8)

@@ -246,3 +246,57 @@ def test_unpack_message_types(oracle):
     # type 4 with icq: "CQ <call>"
     rc, text = oracle.unpack77(payload(4, 0, (38 ** 5 + 7) << 4 | 1))
     assert rc == 0 and text.startswith("CQ ")
+
+
+def test_unpack_against_an_independent_encoder(oracle):
+    """unpack(pack(text)) == text with tests/ft8_spec_pack.py, an encoder written from the published protocol
+    description and not from the unpack code: reaches the branches no reference-held vector reaches."""
+    import ft8_spec_pack as P
+    rng = np.random.default_rng(77)
+    letters = "ABCDEFGHIJKLMNOPQRSTUVWXYZ"
+
+    def call():
+        pfx = str(rng.choice(["K", "W", "G", "F", "DL", "JA", "VK", "9A", "A6", "3D"]))
+        return pfx + str(rng.integers(0, 10)) + "".join(rng.choice(list(letters), size=int(rng.integers(1, 4))))
+
+    def check(payload, expect):
+        rc, text = oracle.unpack77(payload)
+        # (upstream's unpack77 appends "call + blank" per call and then the extra field, which leaves a trailing
+        # blank when the extra field is empty; strtok at rtlsdr_ft8d.c:1509 does not see it)
+        assert rc >= 0 and text.rstrip(" ") == expect and len(text) - len(expect) <= 1, (payload.hex(), text, expect)
+
+    assert P.pack_standard("CQ", "K1JT", "FN20") == bytes.fromhex("000000204dfcdc8a1408")      # the reference's own KAT, :921
+    for _ in range(300):
+        a, b = call(), call()
+        grid = letters[rng.integers(0, 18)] + letters[rng.integers(0, 18)] + f"{rng.integers(0, 100):02d}"
+        check(P.pack_standard(a, b, grid), f"{a} {b} {grid}")
+        check(P.pack_standard(a, b, "R " + grid), f"{a} {b} R {grid}")
+        rpt = int(rng.integers(-30, 31))
+        check(P.pack_standard(a, b, f"{rpt:+03d}"), f"{a} {b} {rpt:+03d}")
+        check(P.pack_standard(a, b, f"R{rpt:+03d}"), f"{a} {b} R{rpt:+03d}")
+        for tail in ("RRR", "RR73", "73", ""):
+            check(P.pack_standard(a, b, tail), f"{a} {b} {tail}".rstrip())
+        check(P.pack_standard(a + "/R", b, grid, i3=1), f"{a}/R {b} {grid}")
+        check(P.pack_standard(a, b + "/P", grid, i3=2), f"{a} {b}/P {grid}")
+        check(P.pack_standard("CQ", b, grid), f"CQ {b} {grid}")
+        check(P.pack_standard("QRZ", b, grid), f"QRZ {b} {grid}")
+        check(P.pack_standard("DE", b, grid), f"DE {b} {grid}")
+        nnn = int(rng.integers(0, 1000))
+        check(P.pack_standard(f"CQ {nnn:03d}", b, grid), f"CQ {nnn:03d} {b} {grid}")
+        word = "".join(rng.choice(list(letters), size=int(rng.integers(1, 5))))
+        check(P.pack_standard("CQ " + word, b, grid), f"CQ {word} {b} {grid}")
+    for _ in range(200):
+        n = int(rng.integers(1, 14))
+        text = "".join(rng.choice(list(P.A_TEXT), size=n)).strip()
+        text = " ".join(text.split()) if False else text
+        if text:
+            check(P.pack_free_text(text), text)
+        hx = "".join(rng.choice(list("01234567"), size=1)) + "".join(rng.choice(list("0123456789ABCDEF"), size=17))
+        rc, t = oracle.unpack77(P.pack_telemetry(hx))
+        assert rc >= 0 and t.lstrip("0") == hx.lstrip("0"), (hx, t)
+        c11 = call() + "/" + str(rng.choice(["P", "MM", "QRP", "7"]))
+        c11 = c11[:11]
+        check(P.pack_nonstandard(c11, hash12=int(rng.integers(0, 4096)), icq=1), f"CQ {c11}")
+        for nrpt, tail in ((0, ""), (1, "RRR"), (2, "RR73"), (3, "73")):
+            check(P.pack_nonstandard(c11, hash12=int(rng.integers(0, 4096)), flip=0, nrpt=nrpt), f"<...> {c11} {tail}".rstrip())
+            check(P.pack_nonstandard(c11, hash12=int(rng.integers(0, 4096)), flip=1, nrpt=nrpt), f"{c11} <...> {tail}".rstrip())
