@@ -54,7 +54,7 @@ def csrc_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "rtlsdr_ft8d_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h", ".c")):
+        if name.endswith((".hip", ".h")):          # device code and its headers (host-only .c files do not change a kernel)
             with open(os.path.join(d, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]

@@ -180,7 +180,7 @@ bool ft8_decode(const waterfall_t *power, const candidate_t *cand, message_t *me
             const int32_t n = 1;
             ft8gpu_candidate c1;
             memcpy(&c1, cand, sizeof c1);
-            g_l2.mag = NULL;                               /* the context's parameters no longer describe the list */
+            g_l2.decoded_iters = 0;                        /* the context's parameters change: the list is re-decoded if asked again */
             if (ft8gpu_set_params(g_ctx, &p) != 0 ||
                 ft8gpu_decode_candidates(g_ctx, power->mag, &c1, &n, 1, &one, FT8GPU_HOST_PTRS) != 0)
                 fprintf(stderr, "ft8gpu: ft8_decode failed: %s\n", ft8gpu_last_error());
