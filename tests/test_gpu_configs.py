@@ -148,3 +148,19 @@ def test_non_overlapped_pipeline_gives_the_same_records(oracle):
             digests.append(hashlib.sha256(d_dev.tobytes() + n_dev.tobytes()).hexdigest())
             assert int(n_dev.sum()) > 8 * n
     assert digests[0] == digests[1]
+
+
+@pytest.mark.parametrize("n", [512, 513, 575, 640, 2049])
+def test_overlapped_pipeline_at_ragged_batch_sizes(n):
+    """batches of at least 512 frames are cut into a small first part and the rest (side stream for the serial
+    kernels); sizes around the thresholds and off the 64-frame grid must give what one launch per stage gives"""
+    import rtlsdr_ft8d_amd as ft8
+    from rtlsdr_ft8d_amd import workload
+    _, tones = workload.message_pool()
+    with ft8.Decoder(device=0, max_frames=n) as dec:
+        iq, _, _ = _synth(ft8, workload, dec, 20000, n, 12, (-16.0, 0.0), tones)
+        d1, n1 = _decode_dev(ft8, dec, iq, n)
+        dec.set_debug_flags(ft8.DBG_NO_OVERLAP)
+        d2, n2 = _decode_dev(ft8, dec, iq, n)
+    assert np.array_equal(n1, n2) and d1.tobytes() == d2.tobytes()
+    assert int(n1.sum()) > 4 * n
