@@ -2,7 +2,7 @@
  * ft8_oracle.c -- CPU ORACLE (test infrastructure only; see ft8_oracle.h for the contract,
  * the list of reference functions restated and the "parity unpinned" statement).
  *
- * Build: gcc -O2 -std=gnu17 -ffp-contract=off -fno-fast-math (oracle/Makefile).
+ * Build: gcc -O3 -std=gnu17 -ffp-contract=off -fno-fast-math (oracle/Makefile; `make asan` for the sanitizer build).
  * -ffp-contract=off matters: the product kernels are compiled the same way so that every
  * float operation below is one IEEE-754 binary32 operation on both sides.
  */
