@@ -10,6 +10,7 @@
 #include <string.h>
 #include <float.h>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -348,7 +349,8 @@ int ft8gpu_create(ft8gpu_ctx **out, int device, int max_frames, const ft8gpu_par
     int prev = -1;
     (void)hipGetDevice(&prev);
     HIP_TRY(hipSetDevice(device));
-    ft8gpu_ctx *c = new ft8gpu_ctx();
+    ft8gpu_ctx *c = new (std::nothrow) ft8gpu_ctx();
+    if (!c) { if (prev >= 0 && prev != device) (void)hipSetDevice(prev); return fail("out of host memory"); }
     c->device = device;
     c->max_frames = max_frames;
     if (params) c->params = *params;
@@ -575,9 +577,15 @@ static int run_shards(ft8gpu_ctx *const *ctxs, int ndev, const float *const *iq_
         if (rc[g]) why[g] = g_err;                       // the error text is thread-local: hand it to the caller's thread
     };
     std::vector<std::thread> threads;
-    for (int g = 1; g < ndev; ++g) if (count[g] > 0) threads.emplace_back(work, g);
+    bool spawn_failed = false;
+    for (int g = 1; g < ndev; ++g) {
+        if (count[g] <= 0) continue;
+        try { threads.emplace_back(work, g); }           // no C++ exception may cross the C ABI
+        catch (...) { spawn_failed = true; work(g); }     // no thread to be had: this shard runs on the calling thread
+    }
     if (count[0] > 0) work(0);                           // shard 0 on the calling thread
     for (auto &t : threads) t.join();
+    (void)spawn_failed;
     for (int g = 0; g < ndev; ++g)
         if (rc[g]) return fail("shard %d of %d (frames [%d, %d)): %s", g, ndev, first[g], first[g] + count[g], why[g].c_str());
     return 0;
