@@ -367,9 +367,18 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
         float c2;
         if (iter > 0) {                                  // wave-uniform
 #pragma unroll
-            for (int r = 0; r < 3; ++r) A[r] = atanh_pair<FAST>(PA[r]);
+            for (int r = 0; r < 2; ++r) A[r] = atanh_pair<FAST>(PA[r]);
             B = atanh_pair<FAST>(PB);
-            c2 = atanh_one<FAST>(pc);
+            // The 18 lanes without a third variable (n = lane + 128 >= 174) sit its three edges out under the EXEC
+            // mask, as do the 45 lanes without a second check row further down.  The instruction count is the same;
+            // what it saves is switching power -- the kernel runs power-limited at about 2.0 GHz, and idle lanes
+            // multiplying spare-row garbage cost clock: 1.7 % of the step in interleaved A/B runs.
+            A[2] = f2{ 0.0f, 0.0f };
+            c2 = 0.0f;
+            if (has[2]) {
+                A[2] = atanh_pair<FAST>(PA[2]);
+                c2 = atanh_one<FAST>(pc);
+            }
         } else {
 #pragma unroll
             for (int r = 0; r < 3; ++r) A[r] = f2{ 0.0f, 0.0f };
@@ -451,17 +460,22 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
         // ---- bits -> checks: toc[m][n_idx] = fast_tanh(-Tnm / 2)
         f2 t[4];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) t[r] = tanh_pair<FAST>(X[r]);
+        for (int r = 0; r < 2; ++r) t[r] = tanh_pair<FAST>(X[r]);
         t[3] = tanh_pair<FAST>(Y);
-        const float tz = tanh_one<FAST>(z);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
+        for (int r = 0; r < 2; ++r) {
             toc[slot[3 * r + 1]] = t[r].x;
             toc[slot[3 * r + 2]] = t[r].y;
         }
         toc[slot[0]] = t[3].x;
         toc[slot[3]] = t[3].y;
-        toc[slot[6]] = tz;
+        if (has[2]) {
+            t[2] = tanh_pair<FAST>(X[2]);
+            const float tz = tanh_one<FAST>(z);
+            toc[slot[7]] = t[2].x;
+            toc[slot[8]] = t[2].y;
+            toc[slot[6]] = tz;
+        }
         return false;
     };
 
@@ -474,6 +488,7 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
         // ---- check rows: ordered products that skip one member, for all members ---------------
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
+            if (rr == 1 && !rvalid[1]) continue;                              // 45 of 64 lanes own no second row (EXEC mask)
             const float4 lo = planeLO[rowidx[rr]], hi = planeHI[rowidx[rr]];
             const float v0 = lo.x, v1 = lo.y, v2 = lo.z, v3 = lo.w, v4 = hi.x, v5 = hi.y, v6 = hi.z;
             const f2 o01 = ((((f2{ v1, v0 } * v2) * v3) * v4) * v5) * v6;   // skip 0 | skip 1
