@@ -378,7 +378,7 @@ def host_legs(dec, iq, spots, nres, B):
     out["host_fed"] = {"frames": m, "ms": round(1e3 * dt, 2), "upload_GBps": round(m * 384000 / dt / 1e9, 1), "records_identical_to_hbm_resident_run": same}
     ncap, npairs = 4, 36_000_000                                         # 15 s at 2.4 Msps
     raw = torch.randint(0, 256, (ncap, 2 * npairs), dtype=torch.uint8, generator=torch.Generator().manual_seed(3)).pin_memory().numpy()
-    dec.rx_decimate(raw[:1])                                             # warm-up
+    dec.rx_decimate(raw)                                                 # warm-up at full size (staging buffers are grown on first use)
     t0 = time.perf_counter()
     frames = dec.rx_decimate(raw)
     t1 = time.perf_counter()
