@@ -126,7 +126,13 @@ int  ft8gpu_set_stream(ft8gpu_ctx *ctx, void *hip_stream);
 #define FT8GPU_DBG_PIPELINE_FORM  2u  /* ft8gpu_decode_candidates runs the form of the LDPC kernel ft8gpu_decode_batch
                                          uses (no exact error count: ldpc_errors is 0 or 83) */
 #define FT8GPU_DBG_NO_OVERLAP     4u  /* one launch per stage for the whole batch: no two-half overlap, no chunked upload */
-int  ft8gpu_set_debug_flags(ft8gpu_ctx *ctx, unsigned flags);
+int  ft8gpu_set_debug_flags(ft8gpu_ctx *ctx, unsigned flags);   /* unknown bits are refused */
+/* Proof by exhaustion behind the LDPC kernel's short division chains (csrc/bp_math.h): fast_tanh / fast_atanh of
+ * ft8_lib ldpc.c (reached through ft8_decode, rtlsdr_ft8d.c:1476) are functions of one float, so all 2^32 inputs are
+ * evaluated on the GPU, fast form against the compiler's IEEE-754 division, on the domain the kernel's guard
+ * establishes.  out[0..6] = tanh inputs, tanh mismatches, atanh inputs, atanh mismatches, packed-form mismatches,
+ * float bits of max |fast_tanh|, one offending input pattern (0 = none).  About 40 ms. */
+int  ft8gpu_selftest_bp_math(ft8gpu_ctx *ctx, uint64_t out[7]);
 int  ft8gpu_set_params(ft8gpu_ctx *ctx, const ft8gpu_params *params);
 int  ft8gpu_enable_timing(ft8gpu_ctx *ctx, int on);
 int  ft8gpu_get_timings(ft8gpu_ctx *ctx, ft8gpu_timings *out, int32_t *nruns);

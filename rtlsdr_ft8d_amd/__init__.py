@@ -63,7 +63,7 @@ ABI_SYMBOLS = [
     "ft8gpu_decode_candidates", "ft8gpu_collect_spots", "ft8gpu_pack77_std", "ft8gpu_encode",
     "ft8gpu_synth_frames", "ft8gpu_synth_frames_at", "ft8gpu_rx_decimate", "ft8gpu_pskreporter_datagrams", "ft8gpu_format_spots",
     "ft8gpu_dev_alloc", "ft8gpu_dev_free", "ft8gpu_memcpy_h2d", "ft8gpu_memcpy_d2h",
-    "ft8gpu_set_debug_flags", "ft8gpu_decode_batch_multi", "ft8gpu_decode_batch_multi_dev",
+    "ft8gpu_set_debug_flags", "ft8gpu_selftest_bp_math", "ft8gpu_decode_batch_multi", "ft8gpu_decode_batch_multi_dev",
     "ft8_find_sync", "ft8_decode", "ft8_encode", "pack77",            # ft8_lib level (include/ft8_lib/ft8/*.h)
     "initFFTW", "freeFFTW", "ft8_subsystem", "ft8gpu_read_raw_iq", "ft8gpu_read_c2", "ft8gpu_write_raw_iq",
 ]
@@ -89,7 +89,17 @@ def load_library():
         raise Ft8GpuError(
             f"{LIB_PATH} is missing: build it with `make -C rtlsdr_ft8d_amd/csrc` "
             "(or __graft_entry__.build()).  There is no CPU fallback.")
-    L = C.CDLL(LIB_PATH)
+    _lib = _declare(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def load_library_at(path):
+    """another build of libft8gpu.so beside the product's (tools/ab_libs.py: A/B of two builds in one process)"""
+    load_library()                                   # the product library first: it fixes which HIP runtime is mapped
+    return _declare(C.CDLL(os.path.abspath(path)))
+
+
+def _declare(L):
     vp, i32p = C.c_void_p, C.POINTER(C.c_int32)
     L.ft8gpu_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(Params)]
     L.ft8gpu_destroy.argtypes = [vp]
@@ -112,6 +122,8 @@ def load_library():
     L.ft8gpu_synth_frames.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, C.c_uint64, vp]
     L.ft8gpu_synth_frames_at.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint64, vp]
     L.ft8gpu_set_debug_flags.argtypes = [vp, C.c_uint]
+    if hasattr(L, "ft8gpu_selftest_bp_math"):             # absent from older builds loaded by load_library_at
+        L.ft8gpu_selftest_bp_math.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.ft8gpu_decode_batch_multi.argtypes = [C.POINTER(vp), C.c_int, vp, C.c_int, vp, vp]
     L.ft8gpu_decode_batch_multi_dev.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp), C.POINTER(C.c_int), vp, vp]
     L.ft8gpu_rx_decimate.argtypes = [vp, vp, C.c_int, C.c_size_t, vp, C.c_int, C.c_int]
@@ -133,13 +145,12 @@ def load_library():
     L.ft8gpu_read_c2.restype = C.c_int32
     L.ft8gpu_write_raw_iq.argtypes = [vp, vp, C.c_char_p]
     L.ft8gpu_write_raw_iq.restype = C.c_int32
-    _lib = L
     return L
 
 
-def _check(rc):
+def _check(rc, lib=None):
     if rc != 0:
-        raise Ft8GpuError(load_library().ft8gpu_last_error().decode(errors="replace"))
+        raise Ft8GpuError((lib or load_library()).ft8gpu_last_error().decode(errors="replace"))
 
 
 def _ptr(a):
@@ -170,8 +181,8 @@ class Decoder:
     """One GPU decoder context (ft8gpu_ctx).  Host arrays are numpy; device arrays are anything
     with ``data_ptr()`` (torch tensors) or raw integer addresses."""
 
-    def __init__(self, device=0, max_frames=64, min_score=10, max_candidates=120, ldpc_iters=20):
-        self.lib = load_library()
+    def __init__(self, device=0, max_frames=64, min_score=10, max_candidates=120, ldpc_iters=20, lib=None):
+        self.lib = lib or load_library()
         self.params = Params(min_score, max_candidates, ldpc_iters)
         self.max_frames = max_frames
         h = C.c_void_p()
@@ -213,6 +224,15 @@ class Decoder:
 
     def set_debug_flags(self, flags):
         _check(self.lib.ft8gpu_set_debug_flags(self.h, int(flags)))
+
+    def selftest_bp_math(self):
+        """exhaustive (2^32 inputs) comparison of the BP kernel's short division chains with the IEEE quotient"""
+        out = (C.c_uint64 * 7)()
+        _check(self.lib.ft8gpu_selftest_bp_math(self.h, out))
+        keys = ("tanh_inputs", "tanh_mismatch", "atanh_inputs", "atanh_mismatch", "pair_mismatch", "tanh_max_bits", "first_bad")
+        d = dict(zip(keys, [int(v) for v in out]))
+        d["tanh_max"] = float(np.array([d["tanh_max_bits"]], np.uint32).view(np.float32)[0])
+        return d
 
     def enable_timing(self, on=True):
         _check(self.lib.ft8gpu_enable_timing(self.h, int(on)))

@@ -1,0 +1,119 @@
+// bp_math.h -- fast_tanh() / fast_atanh() of ft8_lib ldpc.c as the BP kernel evaluates them (decode.hip), and the
+// same code for the exhaustive self-test (bp_selftest.hip).  Device code only.
+//
+// Division.  The reference's a / b is the IEEE-754 correctly rounded quotient.  The compiler's expansion is
+// v_div_scale x2, v_rcp, fma x2, mul, fma x3 (v_div_fmas), v_div_fixup; when v_div_scale does not rescale
+// (|numerator| >= 2^-103, moderate denominator, normal quotient, no special value) scale and fixup are the
+// identity.  Both rational functions compute a AND b from ONE float x by a fixed sequence of IEEE operations, so
+// "does a shorter rcp/fma chain return the same bits?" is a question about 2^32 inputs and is answered by
+// trying them all on the hardware (v_rcp_f32 is a fixed function of its input):
+//   * fast_atanh: q0 = a * rcp(b); q = fma(fma(-b, q0, a), rcp(b), q0) -- three operations after the reciprocal --
+//     equals the IEEE quotient for EVERY x with x == 0 or 2^-59 <= |x| <= 1.05 (990 694 608 inputs);
+//   * fast_tanh: the same chain misses on three magnitudes (0x3bcb9486, 0x3c42d1d7, 0x3dfd692c); with one
+//     Newton step on the reciprocal first (five operations) it equals the IEEE quotient for EVERY x with
+//     x == 0 or 2^-82 <= |x| <= 4.97 (1 413 354 622 inputs; beyond 4.97 the clamp overrides the quotient).
+// (tools/ubench/div_exhaustive.hip tries six chains, profiles/r03_div_exhaustive.json; round 2 used seven
+// operations for both.)  The domains are what decode.hip's per-iteration guard establishes (guard_key); the
+// only difference from the IEEE form is that a zero quotient may carry the other sign, which no later operation
+// observes.  ft8gpu_selftest_bp_math() re-runs the exhaustive comparison on these very functions (all 2^32
+// patterns, about 40 ms) and tests/test_gpu_parity.py requires zero mismatches.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace bpm {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// ---- a / b for a pair ---------------------------------------------------------------------------
+__device__ __forceinline__ f2 rcp_pair(f2 b) {
+    f2 r;
+    r.x = __builtin_amdgcn_rcpf(b.x);
+    r.y = __builtin_amdgcn_rcpf(b.y);
+    return r;
+}
+// raw reciprocal, one residual correction (exact on fast_atanh's domain)
+__device__ __forceinline__ f2 div_pair_3(f2 a, f2 b) {
+    const f2 r0 = rcp_pair(b);
+    const f2 q0 = a * r0;
+    const f2 e1 = pk_fma(-b, q0, a);
+    return pk_fma(e1, r0, q0);
+}
+// Newton step on the reciprocal, one residual correction (exact on fast_tanh's domain)
+__device__ __forceinline__ f2 div_pair_5(f2 a, f2 b) {
+    const f2 r0 = rcp_pair(b);
+    const f2 one = { 1.0f, 1.0f };
+    const f2 e0 = pk_fma(-b, r0, one);
+    const f2 r1 = pk_fma(e0, r0, r0);
+    const f2 q0 = a * r1;
+    const f2 e1 = pk_fma(-b, q0, a);
+    return pk_fma(e1, r1, q0);
+}
+__device__ __forceinline__ f2 div_pair_ieee(f2 a, f2 b) {
+    f2 q;
+    q.x = __fdiv_rn(a.x, b.x);
+    q.y = __fdiv_rn(a.y, b.y);
+    return q;
+}
+// the same chains on one float (the ninth edge of a lane has no partner; a packed instruction costs about 1.7
+// scalar ones on gfx950, so half-empty pairs are not free)
+__device__ __forceinline__ float div_one_3(float a, float b) {
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float q0 = a * r0;
+    const float e1 = __builtin_fmaf(-b, q0, a);
+    return __builtin_fmaf(e1, r0, q0);
+}
+__device__ __forceinline__ float div_one_5(float a, float b) {
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float e0 = __builtin_fmaf(-b, r0, 1.0f);
+    const float r1 = __builtin_fmaf(e0, r0, r0);
+    const float q0 = a * r1;
+    const float e1 = __builtin_fmaf(-b, q0, a);
+    return __builtin_fmaf(e1, r1, q0);
+}
+
+// ---- fast_tanh() of ft8_lib ldpc.c: clamp tests in the reference's order, rational evaluated unconditionally
+// (finite or overridden for every finite x)
+template <bool FAST>
+__device__ __forceinline__ f2 tanh_pair(f2 x) {
+    const f2 x2 = x * x;
+    const f2 a = x * (945.0f + x2 * (105.0f + x2));
+    const f2 b = 945.0f + x2 * (420.0f + x2 * 15.0f);
+    f2 r = FAST ? div_pair_5(a, b) : div_pair_ieee(a, b);
+    // "x < -4.97 -> -1; x > 4.97 -> +1" == "|x| > 4.97 -> copysign(1, x)" (NaN takes neither branch)
+    r.x = (__builtin_fabsf(x.x) > 4.97f) ? __builtin_copysignf(1.0f, x.x) : r.x;
+    r.y = (__builtin_fabsf(x.y) > 4.97f) ? __builtin_copysignf(1.0f, x.y) : r.y;
+    return r;
+}
+template <bool FAST>
+__device__ __forceinline__ float tanh_one(float x) {
+    const float x2 = x * x;
+    const float a = x * (945.0f + x2 * (105.0f + x2));
+    const float b = 945.0f + x2 * (420.0f + x2 * 15.0f);
+    const float r = FAST ? div_one_5(a, b) : __fdiv_rn(a, b);
+    return (__builtin_fabsf(x) > 4.97f) ? __builtin_copysignf(1.0f, x) : r;
+}
+
+// ---- fast_atanh() of ft8_lib ldpc.c
+template <bool FAST>
+__device__ __forceinline__ f2 atanh_pair(f2 x) {
+    const f2 x2 = x * x;
+    const f2 a = x * (945.0f + x2 * (-735.0f + x2 * 64.0f));
+    const f2 b = (945.0f + x2 * (-1050.0f + x2 * 225.0f));
+    return FAST ? div_pair_3(a, b) : div_pair_ieee(a, b);
+}
+template <bool FAST>
+__device__ __forceinline__ float atanh_one(float x) {
+    const float x2 = x * x;
+    const float a = x * (945.0f + x2 * (-735.0f + x2 * 64.0f));
+    const float b = (945.0f + x2 * (-1050.0f + x2 * 225.0f));
+    return FAST ? div_one_3(a, b) : __fdiv_rn(a, b);
+}
+
+// domains of the fast forms (what decode.hip's guard establishes; see guard_key there)
+constexpr float kTanhMinAbs = 0x1p-82f;          // x == 0 or |x| >= 2^-82 (any larger |x|: the clamp takes over beyond 4.97)
+constexpr float kAtanhMinAbs = 0x1p-59f;         // P == 0 or |P| >= 2^-59
+constexpr float kAtanhMaxAbs = 1.05f;            // |P| <= 1.0073^6 < 1.0446: six factors, each at most max|fast_tanh| = 1.00722
+
+}  // namespace bpm

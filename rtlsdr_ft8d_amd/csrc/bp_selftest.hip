@@ -1,0 +1,85 @@
+// bp_selftest.hip -- proof by exhaustion that the short division chains of bp_math.h return the IEEE-754 quotient.
+// fast_tanh / fast_atanh (ft8_lib ldpc.c) are functions of ONE float, so every input the BP kernel's fast path can
+// see is tried: all 2^32 bit patterns, filtered to the domain the kernel's guard establishes, fast form against the
+// compiler's IEEE division, scalar and packed forms alike.  About 40 ms on one MI355X.
+#include "ft8gpu_internal.h"
+#include "bp_math.h"
+
+namespace {
+
+struct Counts {
+    unsigned long long tanh_inputs, tanh_mismatch, atanh_inputs, atanh_mismatch, pair_mismatch;
+    unsigned int tanh_max_bits;         // bits of max |fast_tanh(x)| over the domain (bounds fast_atanh's inputs)
+    unsigned int first_bad;             // one offending bit pattern (0 = none)
+};
+
+// equal bits, or both zero (the fast chains may return the other zero; decode.hip: file header)
+__device__ __forceinline__ bool same(float a, float b) {
+    const uint32_t x = __float_as_uint(a), y = __float_as_uint(b);
+    return x == y || ((x | y) << 1) == 0u || (a != a && b != b);
+}
+
+__global__ __launch_bounds__(256) void bp_math_exhaustive(Counts *out, uint32_t first, uint64_t n) {
+    unsigned long long ti = 0, tm = 0, ai = 0, am = 0, pm = 0;
+    unsigned int tmax = 0, bad = 0;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t bits = first + (uint32_t)i;
+        const float x = __uint_as_float(bits);
+        const float ax = __builtin_fabsf(x);
+        if (!(ax == ax)) continue;
+        const bool in_t = ax == 0.0f || ax >= bpm::kTanhMinAbs;                     // beyond 4.97 the clamp decides: included
+        const bool in_a = (ax == 0.0f || ax >= bpm::kAtanhMinAbs) && ax <= bpm::kAtanhMaxAbs;
+        if (in_t) {
+            ++ti;
+            const float f = bpm::tanh_one<true>(x), r = bpm::tanh_one<false>(x);
+            if (!same(f, r)) { ++tm; bad = bits; }
+            tmax = max(tmax, __float_as_uint(__builtin_fabsf(r)));
+        }
+        if (in_a) {
+            ++ai;
+            if (!same(bpm::atanh_one<true>(x), bpm::atanh_one<false>(x))) { ++am; bad = bits; }
+        }
+        // packed forms: this x beside a partner from elsewhere in the domain (lane-mixing must not matter)
+        const float y = __uint_as_float((bits * 2654435761u) & 0x7FFFFFFFu);
+        const float ay = __builtin_fabsf(y);
+        const bool y_t = (ay == ay) && (ay == 0.0f || ay >= bpm::kTanhMinAbs);
+        const bool y_a = (ay == ay) && (ay == 0.0f || ay >= bpm::kAtanhMinAbs) && ay <= bpm::kAtanhMaxAbs;
+        if (in_t && y_t) {
+            const bpm::f2 f = bpm::tanh_pair<true>(bpm::f2{ x, y }), r = bpm::tanh_pair<false>(bpm::f2{ x, y });
+            if (!same(f.x, r.x) || !same(f.y, r.y)) { ++pm; bad = bits; }
+        }
+        if (in_a && y_a) {
+            const bpm::f2 f = bpm::atanh_pair<true>(bpm::f2{ y, x }), r = bpm::atanh_pair<false>(bpm::f2{ y, x });
+            if (!same(f.x, r.x) || !same(f.y, r.y)) { ++pm; bad = bits; }
+        }
+    }
+    if (ti) atomicAdd(&out->tanh_inputs, ti);
+    if (tm) atomicAdd(&out->tanh_mismatch, tm);
+    if (ai) atomicAdd(&out->atanh_inputs, ai);
+    if (am) atomicAdd(&out->atanh_mismatch, am);
+    if (pm) atomicAdd(&out->pair_mismatch, pm);
+    atomicMax(&out->tanh_max_bits, tmax);
+    if (bad) atomicMax(&out->first_bad, bad);
+}
+
+}  // namespace
+
+// out[0..6]: tanh inputs, tanh mismatches, atanh inputs, atanh mismatches, packed-form mismatches,
+//            bits of max |fast_tanh|, one offending input (0 = none)
+hipError_t run_bp_math_selftest(uint64_t out[7], hipStream_t s) {
+    Counts *d = nullptr, h;
+    hipError_t e = hipMalloc(&d, sizeof(Counts));
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(d, 0, sizeof(Counts), s);
+    for (uint32_t part = 0; part < 16 && e == hipSuccess; ++part) {
+        hipLaunchKernelGGL(bp_math_exhaustive, dim3(256 * 32), dim3(256), 0, s, d, part << 28, (uint64_t)1 << 28);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    if (e != hipSuccess) return e;
+    out[0] = h.tanh_inputs; out[1] = h.tanh_mismatch; out[2] = h.atanh_inputs; out[3] = h.atanh_mismatch;
+    out[4] = h.pair_mismatch; out[5] = h.tanh_max_bits; out[6] = h.first_bad;
+    return hipSuccess;
+}

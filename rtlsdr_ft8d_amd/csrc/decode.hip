@@ -20,25 +20,28 @@
 //     accesses are conflict-free ds_read/write_b128).
 //   * hard decisions are gathered with three __ballot()s; a parity check is popcount(word & row
 //     mask); the error count is the popcount of a ballot.  Exit conditions are wave-uniform.
-//   * divisions: the IEEE-754 correctly rounded quotient is required for parity.  The compiler's
-//     expansion is v_div_scale x2, v_rcp, fma x2, mul, fma x3 (v_div_fmas), v_div_fixup.  When
-//     v_div_scale does not rescale (|numerator| >= 2^-103, moderate denominator, quotient normal)
-//     and no special value is involved, scale and fixup are the identity and the quotient is the
-//     plain rcp/fma chain.  Denominators here are moderate; a wave-uniform guard (see guard_key)
-//     proves that every numerator is 0 or far above the rescaling threshold, and only then takes
-//     the packed rcp/fma chain (bitwise the same quotient, except that a zero quotient may carry
-//     the other sign, which no later operation can observe); otherwise the compiler's division.
+//   * divisions: the IEEE-754 correctly rounded quotient is required for parity.  bp_math.h holds the two
+//     rational functions with the shortest rcp/fma chains that were shown BY EXHAUSTION over all 2^32 inputs to
+//     return the IEEE quotient on the domain a wave-uniform guard (see guard_key) establishes -- three operations
+//     after v_rcp_f32 for fast_atanh, five for fast_tanh (round 2: seven each); outside that domain the
+//     compiler's division runs.  (The only difference: a zero quotient may carry the other sign, which no later
+//     operation can observe.)
 //   * every other float expression is written in the reference's operation order and compiled
 //     with -ffp-contract=off (fused operations appear only inside the division chain above).
 #include "ft8gpu_internal.h"
 #include "ft8_tables.h"
 #include "unpack_dev.h"
+#include "bp_math.h"
 #include <stdlib.h>
 #include <type_traits>
 
 namespace {
 
-typedef float f2 __attribute__((ext_vector_type(2)));
+using bpm::f2;
+using bpm::tanh_pair;
+using bpm::tanh_one;
+using bpm::atanh_pair;
+using bpm::atanh_one;
 
 // The pipeline only needs to know WHETHER a hard decision satisfies all 83 checks (the error count
 // matters to nobody once it is non-zero).  The XOR of any set of parity rows is itself a parity
@@ -71,7 +74,6 @@ __host__ __device__ constexpr int slot_index(int m, int pos) {
     return pos < 4 ? 4 * m + pos : 4 * kRows + 4 * m + (pos - 4);
 }
 
-__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 // min(|a|, |b|, |c|) in one instruction (no canonicalising copies of the operands)
 __device__ __forceinline__ float min3_abs(float a, float b, float c) {
     float r;
@@ -83,81 +85,6 @@ __device__ __forceinline__ float add_f32(float a, float b) {
     float r;
     asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
-}
-
-// a / b, correctly rounded, for a pair; preconditions in the file header
-__device__ __forceinline__ f2 div_pair_fast(f2 a, f2 b) {
-    f2 r0;
-    r0.x = __builtin_amdgcn_rcpf(b.x);
-    r0.y = __builtin_amdgcn_rcpf(b.y);
-    const f2 one = { 1.0f, 1.0f };
-    const f2 e0 = pk_fma(-b, r0, one);
-    const f2 r1 = pk_fma(e0, r0, r0);
-    const f2 q0 = a * r1;
-    const f2 e1 = pk_fma(-b, q0, a);
-    const f2 q1 = pk_fma(e1, r1, q0);
-    const f2 e2 = pk_fma(-b, q1, a);
-    return pk_fma(e2, r1, q1);
-}
-
-__device__ __forceinline__ f2 div_pair_ieee(f2 a, f2 b) {
-    f2 q;
-    q.x = __fdiv_rn(a.x, b.x);
-    q.y = __fdiv_rn(a.y, b.y);
-    return q;
-}
-
-// fast_tanh() of ft8_lib ldpc.c for a pair: clamp tests in the reference's order, rational
-// evaluated unconditionally (finite for every finite x)
-template <bool FAST>
-__device__ __forceinline__ f2 tanh_pair(f2 x) {
-    const f2 x2 = x * x;
-    const f2 a = x * (945.0f + x2 * (105.0f + x2));
-    const f2 b = 945.0f + x2 * (420.0f + x2 * 15.0f);
-    f2 r = FAST ? div_pair_fast(a, b) : div_pair_ieee(a, b);
-    // "x < -4.97 -> -1; x > 4.97 -> +1" == "|x| > 4.97 -> copysign(1, x)" (NaN takes neither branch)
-    r.x = (__builtin_fabsf(x.x) > 4.97f) ? __builtin_copysignf(1.0f, x.x) : r.x;
-    r.y = (__builtin_fabsf(x.y) > 4.97f) ? __builtin_copysignf(1.0f, x.y) : r.y;
-    return r;
-}
-
-// fast_atanh() of ft8_lib ldpc.c for a pair
-template <bool FAST>
-__device__ __forceinline__ f2 atanh_pair(f2 x) {
-    const f2 x2 = x * x;
-    const f2 a = x * (945.0f + x2 * (-735.0f + x2 * 64.0f));
-    const f2 b = (945.0f + x2 * (-1050.0f + x2 * 225.0f));
-    return FAST ? div_pair_fast(a, b) : div_pair_ieee(a, b);
-}
-
-// The ninth edge of a lane has no partner: the same functions on one float (a packed instruction
-// costs about 1.7 scalar ones on gfx950, so half-empty pairs are not free)
-__device__ __forceinline__ float div_one_fast(float a, float b) {
-    const float r0 = __builtin_amdgcn_rcpf(b);
-    const float e0 = __builtin_fmaf(-b, r0, 1.0f);
-    const float r1 = __builtin_fmaf(e0, r0, r0);
-    const float q0 = a * r1;
-    const float e1 = __builtin_fmaf(-b, q0, a);
-    const float q1 = __builtin_fmaf(e1, r1, q0);
-    const float e2 = __builtin_fmaf(-b, q1, a);
-    return __builtin_fmaf(e2, r1, q1);
-}
-
-template <bool FAST>
-__device__ __forceinline__ float tanh_one(float x) {
-    const float x2 = x * x;
-    const float a = x * (945.0f + x2 * (105.0f + x2));
-    const float b = 945.0f + x2 * (420.0f + x2 * 15.0f);
-    const float r = FAST ? div_one_fast(a, b) : __fdiv_rn(a, b);
-    return (__builtin_fabsf(x) > 4.97f) ? __builtin_copysignf(1.0f, x) : r;
-}
-
-template <bool FAST>
-__device__ __forceinline__ float atanh_one(float x) {
-    const float x2 = x * x;
-    const float a = x * (945.0f + x2 * (-735.0f + x2 * 64.0f));
-    const float b = (945.0f + x2 * (-1050.0f + x2 * 225.0f));
-    return FAST ? div_one_fast(a, b) : __fdiv_rn(a, b);
 }
 
 // Guard key of a value: (bits << 1) - 1 as unsigned.  Zero maps to 0xFFFFFFFF, every other value to

@@ -417,8 +417,17 @@ int ft8gpu_set_params(ft8gpu_ctx *c, const ft8gpu_params *p) {
 
 int ft8gpu_set_debug_flags(ft8gpu_ctx *c, unsigned flags) {
     CHECK_COMMON(c, 0);
+    if (flags & ~(FT8GPU_DBG_FORCE_IEEE_DIV | FT8GPU_DBG_PIPELINE_FORM | FT8GPU_DBG_NO_OVERLAP))
+        return fail("ft8gpu_set_debug_flags: unknown bits 0x%x", flags & ~(FT8GPU_DBG_FORCE_IEEE_DIV | FT8GPU_DBG_PIPELINE_FORM | FT8GPU_DBG_NO_OVERLAP));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->debug_flags = flags;
+    return 0;
+}
+
+int ft8gpu_selftest_bp_math(ft8gpu_ctx *c, uint64_t out[7]) {
+    if (!out) return fail("NULL argument");
+    CHECK_COMMON(c, 0);
+    HIP_TRY(run_bp_math_selftest(out, c->stream));
     return 0;
 }
 

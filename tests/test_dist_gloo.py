@@ -102,3 +102,49 @@ def test_frame_description_independent_of_world_size():
             lo, hi = workload.shard_range(12, r, world)
             parts.append(workload.frame_signals(lo, hi - lo, 5, tones)[0])
         assert np.array_equal(np.concatenate(parts), whole)
+
+
+def _run_bench(*argv, env_extra=None):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    return p.returncode, [json.loads(ln) for ln in lines], p.stderr
+
+
+def test_bench_self_launches_its_ranks_as_a_plain_command():
+    """`python bench.py --gpus 2` with no RANK/WORLD_SIZE in the environment must start its own two ranks (fresh
+    child processes through torch.distributed.run, free port on 127.0.0.1), relay ONE JSON line and exit 0;
+    --backend gloo --dry runs the real shard_range + SpotExchange on CPU tensors without touching a GPU"""
+    rc, lines, err = _run_bench("--gpus", "2", "--backend", "gloo", "--dry", "--frames", "48", "--steps", "3", "--warmup", "1")
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["backend"] == "gloo" and line["dry"] is True
+    assert line["dry_gather_identical_on_all_ranks"] is True
+    assert line["config"]["global_frames"] == 96 and line["config"]["frames_per_gpu"] == 48
+    assert line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+
+
+def test_bench_under_an_external_torchrun_still_works():
+    """the driver's own form: torch.distributed.run starts bench.py, which must NOT launch again"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--backend", "gloo", "--dry", "--frames", "16", "--steps", "2", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1 and lines[0]["ranks"] == 2 and lines[0]["dry_gather_identical_on_all_ranks"] is True
+
+
+def test_bench_launcher_reports_a_failing_rank():
+    """a rank that dies makes the plain command exit non-zero (here: world size mismatch inside the children)"""
+    rc, lines, err = _run_bench("--gpus", "2", "--backend", "gloo", "--frames", "8")     # gloo without --dry is refused by every rank
+    assert rc != 0 and not lines
+    assert "2-rank job failed" in err

@@ -193,3 +193,51 @@ def test_two_ranks_share_gpu0_and_match_the_single_process_batch():
         assert p.exitcode == 0
     assert [r[1] for r in res] == [True, True]
     assert (res[0][2], res[0][3], res[1][2], res[1][3]) == (0, 256, 256, 512)
+
+
+# ---- configs[3] at its size on one GPU ------------------------------------------------------------
+def test_config4_32768_frames_eight_shards(oracle):
+    """BASELINE configs[3]: 32 768 frames = 8 contiguous shards of 4096.  With one GPU on the box the eight shards
+    are eight contexts on GPU 0 (own streams and HBM buffers each; 12.6 GB of IQ resident), decoded through
+    ft8gpu_decode_batch_multi_dev (eight host threads, records gathered at their frame offsets), and must be
+    byte-identical to ONE 4096-frame context walking the same 32 768 frames chunk by chunk; the oracle agrees on
+    frames spread over all shards; about 12 messages decode per frame."""
+    import torch
+    import rtlsdr_ft8d_amd as ft8
+    from rtlsdr_ft8d_amd import workload
+    S, B = 8, 4096
+    total = S * B
+    decs = [ft8.Decoder(device=0, max_frames=B) for _ in range(S)]
+    try:
+        shards = []
+        for g in range(S):
+            lo, hi = workload.shard_range(total, g, S)
+            assert (lo, hi) == (g * B, (g + 1) * B)
+            shards.append(_job(ft8, workload, decs[g], lo, B))
+        got, got_n = ft8.decode_batch_multi_dev(decs, shards, [B] * S)
+        again, again_n = ft8.decode_batch_multi_dev(decs, shards, [B] * S, decodes=np.zeros_like(got))
+        assert np.array_equal(again_n, got_n) and again.tobytes() == got.tobytes()          # deterministic under 8-way concurrency
+        # one context, chunk by chunk, device-resident records
+        spots = torch.zeros((B, 1400), dtype=torch.uint8, device="cuda")
+        nres = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        for g in range(S):
+            spots.zero_()
+            torch.cuda.synchronize()
+            decs[0].decode_batch_dev(shards[g], B, spots, nres)
+            decs[0].synchronize()
+            assert np.array_equal(nres.cpu().numpy(), got_n[g * B:(g + 1) * B]), f"shard {g}: counts"
+            assert spots.cpu().numpy().tobytes() == got[g * B:(g + 1) * B].tobytes(), f"shard {g}: records"
+        per_frame = float(got_n.mean())
+        assert 11.0 < per_frame < 13.5, per_frame
+        # the oracle on 32 frames, four per shard
+        picks = [g * B + k for g in range(S) for k in (0, 1365, 2730, 4095)]
+        for f in picks:
+            g, k = divmod(f, B)
+            fr = shards[g][k].cpu().numpy()
+            rdec, rn = oracle.subsystem(fr[0], fr[1])
+            assert got_n[f] == rn, f
+            assert got[f][:rn].tobytes() == rdec[:rn].tobytes(), f
+    finally:
+        for d in decs:
+            d.close()

@@ -481,6 +481,24 @@ def test_decode_with_forced_ieee_division(oracle):
         assert n[k] == rn and dec[k].tobytes() == rdec.tobytes()
 
 
+def test_bp_division_chains_by_exhaustion():
+    """fast_tanh / fast_atanh (ft8_lib ldpc.c) are functions of ONE float, so the BP kernel's short rcp/fma division
+    chains (csrc/bp_math.h: three operations after v_rcp_f32 for atanh, five for tanh) are checked against the
+    compiler's IEEE-754 division on EVERY input of the fast path's domain -- all 2^32 bit patterns, scalar and
+    packed forms.  Zero mismatches is the proof the parity claim of the LDPC kernel rests on.  Also bounds
+    max|fast_tanh|, which bounds fast_atanh's inputs (six factors per check row at most)."""
+    import rtlsdr_ft8d_amd as ft8
+    with ft8.Decoder(device=0, max_frames=1) as d:
+        r = d.selftest_bp_math()
+    assert r["tanh_inputs"] > 2_000_000_000 and r["atanh_inputs"] > 900_000_000, r
+    assert r["tanh_mismatch"] == 0 and r["atanh_mismatch"] == 0 and r["pair_mismatch"] == 0, r
+    assert r["first_bad"] == 0
+    assert 1.0 < r["tanh_max"] < 1.0075 and r["tanh_max"] ** 6 < 1.05, r          # 1.05 = bpm::kAtanhMaxAbs
+    with ft8.Decoder(device=0, max_frames=1) as d:
+        with pytest.raises(ft8.Ft8GpuError, match="unknown bits"):
+            d.set_debug_flags(8)
+
+
 def test_decode_pipeline_form_of_the_kernel(oracle):
     """the batch pipeline runs the BP kernel without the exact error count: a scalar group-parity test
     screens every hard decision and only survivors get the exact per-row check.  With
