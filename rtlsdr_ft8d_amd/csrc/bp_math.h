@@ -73,6 +73,33 @@ __device__ __forceinline__ float div_one_5(float a, float b) {
     return __builtin_fmaf(e1, r1, q0);
 }
 
+// fast_tanh's clamp: "x < -4.97 -> -1; x > 4.97 -> +1" == "|x| > 4.97 -> copysign(1, x)" (NaN takes neither branch).
+// As the compiler writes it this is v_cmp + v_bfi + v_cndmask per value.  Here the compare narrows EXEC itself
+// (v_cmpx) and the copysign is written in place under that mask: one VALU instruction less per value -- nine per BP
+// iteration -- for two scalar moves that save and restore EXEC (the scalar unit has the slack).
+__device__ __forceinline__ float clamp_497(float q, float x) {
+    unsigned long long saved;
+    asm("s_mov_b64 %1, exec\n\t"
+        "v_cmpx_gt_f32_e64 vcc, |%2|, %3\n\t"
+        "v_bfi_b32 %0, %4, 1.0, %2\n\t"
+        "s_mov_b64 exec, %1"
+        : "+v"(q), "=&s"(saved) : "v"(x), "s"(4.97f), "s"(0x7fffffffu) : "vcc");
+    return q;
+}
+__device__ __forceinline__ f2 clamp_497(f2 q, f2 x) {
+    unsigned long long saved;
+    float q0 = q.x, q1 = q.y;
+    asm("s_mov_b64 %2, exec\n\t"
+        "v_cmpx_gt_f32_e64 vcc, |%3|, %5\n\t"
+        "v_bfi_b32 %0, %6, 1.0, %3\n\t"
+        "s_mov_b64 exec, %2\n\t"
+        "v_cmpx_gt_f32_e64 vcc, |%4|, %5\n\t"
+        "v_bfi_b32 %1, %6, 1.0, %4\n\t"
+        "s_mov_b64 exec, %2"
+        : "+v"(q0), "+v"(q1), "=&s"(saved) : "v"(x.x), "v"(x.y), "s"(4.97f), "s"(0x7fffffffu) : "vcc");
+    return f2{ q0, q1 };
+}
+
 // ---- fast_tanh() of ft8_lib ldpc.c: clamp tests in the reference's order, rational evaluated unconditionally
 // (finite or overridden for every finite x)
 template <bool FAST>
@@ -80,19 +107,14 @@ __device__ __forceinline__ f2 tanh_pair(f2 x) {
     const f2 x2 = x * x;
     const f2 a = x * (945.0f + x2 * (105.0f + x2));
     const f2 b = 945.0f + x2 * (420.0f + x2 * 15.0f);
-    f2 r = FAST ? div_pair_5(a, b) : div_pair_ieee(a, b);
-    // "x < -4.97 -> -1; x > 4.97 -> +1" == "|x| > 4.97 -> copysign(1, x)" (NaN takes neither branch)
-    r.x = (__builtin_fabsf(x.x) > 4.97f) ? __builtin_copysignf(1.0f, x.x) : r.x;
-    r.y = (__builtin_fabsf(x.y) > 4.97f) ? __builtin_copysignf(1.0f, x.y) : r.y;
-    return r;
+    return clamp_497(FAST ? div_pair_5(a, b) : div_pair_ieee(a, b), x);
 }
 template <bool FAST>
 __device__ __forceinline__ float tanh_one(float x) {
     const float x2 = x * x;
     const float a = x * (945.0f + x2 * (105.0f + x2));
     const float b = 945.0f + x2 * (420.0f + x2 * 15.0f);
-    const float r = FAST ? div_one_5(a, b) : __fdiv_rn(a, b);
-    return (__builtin_fabsf(x) > 4.97f) ? __builtin_copysignf(1.0f, x) : r;
+    return clamp_497(FAST ? div_one_5(a, b) : __fdiv_rn(a, b), x);
 }
 
 // ---- fast_atanh() of ft8_lib ldpc.c
