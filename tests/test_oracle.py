@@ -300,3 +300,39 @@ def test_unpack_against_an_independent_encoder(oracle):
         for nrpt, tail in ((0, ""), (1, "RRR"), (2, "RR73"), (3, "73")):
             check(P.pack_nonstandard(c11, hash12=int(rng.integers(0, 4096)), flip=0, nrpt=nrpt), f"<...> {c11} {tail}".rstrip())
             check(P.pack_nonstandard(c11, hash12=int(rng.integers(0, 4096)), flip=1, nrpt=nrpt), f"{c11} <...> {tail}".rstrip())
+
+
+# ---- a third, independent restatement of the ft8_lib stages (numpy) ---------------
+def test_oracle_against_the_independent_numpy_restatement(oracle):
+    """tests/ft8_spec_decode.py restates ft8_find_sync and ft8_decode from SURVEY.md Appendix A.2-A.4 in numpy
+    float32 without looking at oracle/ft8_oracle.c.  On the golden frames and the reference's self-test frame the
+    two writings must agree on: all 35 856 sync scores, the candidate list IN ORDER at caps 120 and 480 (and at a
+    cap small enough to force evictions and ties), and for every candidate the LLRs bit for bit, the minimum parity
+    error count, the number of BP iterations entered and the 91 packed bits of the last hard decision."""
+    import ft8_spec_decode as spec
+    bp = spec.BP()
+    g = load("frames.json")
+    enc = S.oracle_encode_fn(oracle)
+    frames = [np.stack(oracle.selftest_signal())]
+    frames += [S.make_frame(fr["seed"], fr["nsig"], enc, snr_range=tuple(fr["snr_range"]), cq_fraction=fr["cq_fraction"])[0]
+               for fr in g["frames"]]
+    checked = iterated = 0
+    for iq in frames:
+        mag = oracle.waterfall(iq[0], iq[1])
+        sc = spec.score_map(mag)
+        assert np.array_equal(sc.astype(np.int16), oracle.score_map(mag))
+        for cap, min_score in ((120, 10), (480, 10), (7, 10), (120, 0)):
+            mine = spec.find_sync(mag, cap, min_score, scores=sc)
+            theirs = cand_list(oracle.find_sync(mag, cap, min_score))
+            assert [list(c) for c in mine] == theirs, (cap, min_score)
+        cands = oracle.find_sync(mag)
+        for k, c in enumerate(spec.find_sync(mag, 120, 10, scores=sc)):
+            ll = spec.normalize_logl(spec.extract_likelihood(mag, c))
+            assert ll.tobytes() == oracle.llr(mag, cands[k:k + 1]).tobytes()
+            for iters in (20, 3):
+                errors, entered, a91 = spec.decode_candidate(bp, mag, c, iters)
+                s = oracle.decode(mag, cands[k:k + 1], iters)
+                assert (errors, entered, a91) == (s["ldpc_errors"], s["iters"], s["a91"]), (k, iters)
+            checked += 1
+            iterated += entered > 0
+    assert checked > 150 and iterated > 100          # most candidates really ran message updates
