@@ -87,6 +87,7 @@ def parse_args(argv=None):
     ap.add_argument("--dry", action="store_true",
                     help="no GPU work: every rank fills its shard's spot buffers with a pattern derived from the global frame index and "
                          "runs the real exchange; checks launcher, sharding and gather (CPU tensors, gloo)")
+    ap.add_argument("--no-clock-sampler", action="store_true", help="do not poll the GPU's sysfs clock / power files during the timed region")
     ap.add_argument("--shards", type=int, default=8, help="configs[3] on one GPU: number of contexts / shards")
     return ap.parse_args(argv)
 
@@ -129,11 +130,13 @@ class ClockSampler:
     """best-effort shader clock / socket power of GPU `index` while the timed region runs (sysfs, 20 ms period);
     every field is null when the box does not expose the files to an ordinary user"""
 
-    def __init__(self, index):
+    def __init__(self, index, enabled=True):
         import glob
         self.sclk, self.power = [], []
         self.clk_file = self.pow_file = None
-        try:                                    # the box exposes every GPU of the host in sysfs: find ours by PCI address
+        try:
+            if not enabled:
+                raise OSError("disabled")                                    # the box exposes every GPU of the host in sysfs: find ours by PCI address
             import torch
             pr = torch.cuda.get_device_properties(index)
             bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
@@ -299,11 +302,13 @@ def main():
         return
 
     dec = ft8.Decoder(device=local_rank, max_frames=B, min_score=10, max_candidates=maxc, ldpc_iters=20)
-    # one explicit torch stream carries both the decoder kernels and the RCCL gather, so that the
-    # collective is ordered after the kernels that produce the spot records
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    dec.set_stream(stream.cuda_stream)
+    # The decoder keeps its OWN stream (its main / side streams are created together and sit on distinct hardware
+    # queues; on a borrowed torch stream the same pipeline measured 1.48 instead of 1.28 ms at 1024 frames, cap 480).
+    # torch sees that stream as an ExternalStream (events, waits); the RCCL gather is issued from a torch stream that
+    # waits for the decoder's stream first, and the decoder waits for that stream before it rewrites a buffer.
+    stream = torch.cuda.ExternalStream(dec.stream_handle(), device=dev)
+    coll_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(coll_stream)
 
     # ---- synthetic frames, generated in HBM (not timed); global frame g is the same samples for any world size
     _, pool_tones = workload.message_pool()
@@ -320,14 +325,19 @@ def main():
     # spot records: two buffers per rank; the exchange of step k (one asynchronous RCCL all-gather of
     # records + counts) runs under the kernels of step k + 1 and is drained inside the timed region
     exch = workload.SpotExchange(B, world, dev, collective=use_dist)
+    torch.cuda.synchronize()                            # the buffers were zero-filled on torch's stream
     spots, nres = exch.buffers(0)
     state = {"k": 0}
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
 
     def step():
         k = state["k"]
-        s_buf, n_buf = exch.buffers(k)                  # waits for the exchange that last used this buffer
+        s_buf, n_buf = exch.buffers(k)                  # (the collective stream) waits for the exchange that last used this buffer
+        if use_dist:
+            stream.wait_stream(coll_stream)             # ... and the decoder for the collective stream
         dec.decode_batch_dev(iq, B, s_buf, n_buf)
+        if use_dist:
+            coll_stream.wait_stream(stream)             # the gather is ordered behind the kernels that produce the records
         exch.launch(k)                                  # the whole job's spot list on every rank
         state["k"] = k + 1
 
@@ -341,7 +351,7 @@ def main():
         step()
     fence()
     dec.enable_timing(True)          # stage events are recorded on the stream, read after the fence
-    with ClockSampler(local_rank) as clk:
+    with ClockSampler(local_rank, not args.no_clock_sampler) as clk:
         t0 = time.perf_counter()
         step_ev[0].record(stream)
         for i in range(args.steps):
@@ -503,11 +513,13 @@ def run_config1(args, out, dec, iq, B, maxc, stream, dev):
         ev[1].record(stream)
         dec.find_sync_dev(mag, B, cands, counts)
         ev[2].record(stream)
+        cur = torch.cuda.current_stream(dev)            # the copies run on torch's stream, behind the decoder's kernels
+        cur.wait_stream(stream)
         h_mag.copy_(mag, non_blocking=True)
         h_cands.copy_(cands, non_blocking=True)
         h_counts.copy_(counts, non_blocking=True)
-        ev[3].record(stream)
-        stream.synchronize()
+        ev[3].record(cur)
+        cur.synchronize()
         t = time.perf_counter()
         res["dec"], res["n"] = oracle_lib.decode_from_candidates_batch(
             h_mag.numpy(), h_cands.numpy().view(oracle_lib.CAND_DTYPE).reshape(B, maxc), h_counts.numpy(), p, cores)
@@ -533,8 +545,10 @@ def run_config1(args, out, dec, iq, B, maxc, stream, dev):
     gpu_ms = stage["waterfall_ms"] + stage["sync_heap_ms"] + stage["d2h_ms"]
     dom_ms = stage["waterfall_ms"]
     achieved = BYTES_PER_FRAME_CFG1 * B / (dom_ms * 1e-3) / 1e9
+    pmc = pmc_figures("waterfall", B, 1, dom_ms, 1)
     out["roofline"] = {"bound": "hbm", "kernel": "waterfall", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                       "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None, "kernel_ms": round(dom_ms, 4),
+                       "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": pmc.get("traffic"), "valu_busy_frac_pmc": pmc.get("valu_busy"),
+                       "kernel_hbm_GBps_from_traffic": pmc.get("kernel_hbm_GBps"), "pmc_from": pmc.get("pmc_from"), "kernel_ms": round(dom_ms, 4),
                        "algorithmic_bytes_per_launch": BYTES_PER_FRAME_CFG1 * B,
                        "stage_ms": {k: round(v, 4) for k, v in stage.items()},
                        "gpu_part_frames_per_s": round(B / (gpu_ms * 1e-3), 1),
@@ -549,26 +563,26 @@ def run_config1(args, out, dec, iq, B, maxc, stream, dev):
 
 def pmc_figures(kernel, frames, launches, ms_per_launch, config=2):
     """PMC-derived figures of the dominant kernel from the committed rocprofv3 summaries (profiles/pmc_traffic.json,
-    profiles/pmc_counters.json: FETCH_SIZE / WRITE_SIZE / SQ passes over this very command, tools/gpu_round.sh).
-    They describe the kernel sources they were collected on: the summary carries a hash of csrc/ and the figures
-    are reported only while it matches the tree this bench runs from (and the launch size); otherwise null."""
+    profiles/pmc_counters.json: FETCH_SIZE / WRITE_SIZE / SQ passes over this very command, tools/gpu_round.sh; the
+    entries of configs[1] and configs[4] sit under "config1" / "config4").  They describe the kernel sources they were
+    collected on: the summary carries a hash of csrc/ and the figures are reported only while it matches the tree this
+    bench runs from (and the launch size); otherwise null."""
     none = {"traffic": None, "valu_busy": None, "valu_frac": None, "kernel_hbm_GBps": None, "pmc_from": None}
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             t = json.load(f)
-        with open(os.path.join(ROOT, "profiles", "pmc_counters.json")) as f:
-            c = json.load(f)
     except (OSError, ValueError):
         return none
-    e = t.get(kernel, {})
+    sect = t if config == 2 else t.get(f"config{config}", {})
+    e = sect.get(kernel, {})
     if not e or e.get("frames_per_launch") != frames // launches or t.get("csrc_sha") != csrc_hash():
         return none
     traffic = int(e["hbm_bytes_per_launch"])
-    insts = c.get(kernel, {}).get("SQ_INSTS_VALU")
+    insts = e.get("SQ_INSTS_VALU")
     return {"traffic": traffic, "valu_busy": e.get("valu_busy_frac"),
             "valu_frac": round(insts * 64 / (ms_per_launch * 1e-3) / FP32_VALU_PEAK, 4) if insts else None,
             "kernel_hbm_GBps": round(traffic / (ms_per_launch * 1e-3) / 1e9, 1),
-            "pmc_from": f"profiles/pmc_traffic.json + pmc_counters.json @ csrc {t.get('csrc_sha')}"}
+            "pmc_from": f"profiles/pmc_traffic.json{'' if config == 2 else ' [config%d]' % config} @ csrc {t.get('csrc_sha')}"}
 
 
 def usable_cores():

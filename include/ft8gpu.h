@@ -121,6 +121,12 @@ void ft8gpu_destroy(ft8gpu_ctx *ctx);
  * null stream explicitly. */
 int  ft8gpu_set_stream(ft8gpu_ctx *ctx, void *hip_stream);
 #define FT8GPU_STREAM_LEGACY ((void *)1)
+/* The hipStream_t (as void*) the context enqueues on, so that a caller can order its own work behind the decoder's
+ * (hipStreamWaitEvent / an RCCL collective) without moving the decoder onto a foreign stream: the context's streams
+ * are created together and map to distinct hardware queues, which the overlap of the heap / spots kernels with the
+ * throughput kernels relies on (measured: the same pipeline takes 1.48 ms on a borrowed framework stream against 1.28 ms
+ * on the context's own at 1024 frames, cap 480). */
+void *ft8gpu_get_stream(ft8gpu_ctx *ctx);
 /* test hooks, per context (any combination; 0 = product behaviour) */
 #define FT8GPU_DBG_FORCE_IEEE_DIV 1u  /* LDPC kernel: the compiler's IEEE division everywhere (the guard's fallback path) */
 #define FT8GPU_DBG_PIPELINE_FORM  2u  /* ft8gpu_decode_candidates runs the form of the LDPC kernel ft8gpu_decode_batch
@@ -165,6 +171,23 @@ int ft8gpu_decode_batch_multi(ft8gpu_ctx *const *ctxs, int ndev, const float *iq
  * e.g. synthesised or decimated there); records are gathered into the host arrays in shard order. */
 int ft8gpu_decode_batch_multi_dev(ft8gpu_ctx *const *ctxs, int ndev, const float *const *iq_dev,
                                   const int *nframes_dev, struct decoder_results *decodes, int32_t *n_results);
+
+/* Device-resident gather of the spot list over RCCL / xGMI: after every GPU g has decoded its shard
+ * into its own HBM (ft8gpu_decode_batch with FT8GPU_DEVICE_PTRS: decodes_dev[g] = [frames_per_dev][50] records,
+ * n_results_dev[g] = [frames_per_dev] counts), ONE grouped all-gather per buffer leaves the whole job's list, in shard
+ * order, on EVERY GPU: all_decodes_dev[g] = [ndev * frames_per_dev][50], all_n_results_dev[g] = [ndev * frames_per_dev].
+ * The collectives are enqueued on each context's own stream (ordered behind the kernels that produced the records; the
+ * host is not synchronised: ft8gpu_synchronize(ctxs[g]) waits).  Single-process RCCL (ncclCommInitAll over the contexts'
+ * devices, created on first use, one rank per GPU -- two contexts on one GPU are refused); librccl is bound at run time,
+ * so -1 with "RCCL unavailable" on a box without it.  Equal shard sizes only (pad the last shard).  Replaces nothing in
+ * the reference (single decoder thread, rtlsdr_ft8d.c:221-285); the host-side gather of ft8gpu_decode_batch_multi is what
+ * a daemon consumes.  ft8gpu_gather_shutdown() destroys the communicators. */
+int  ft8gpu_gather_spots(ft8gpu_ctx *const *ctxs, int ndev, const struct decoder_results *const *decodes_dev,
+                         const int32_t *const *n_results_dev, int frames_per_dev,
+                         struct decoder_results *const *all_decodes_dev, int32_t *const *all_n_results_dev);
+void ft8gpu_gather_shutdown(void);
+/* host worker threads the multi-GPU entries keep alive between calls (created on first use; diagnostic) */
+int  ft8gpu_shard_workers(void);
 
 /* ---- stage entries (same data, stage by stage; used by the parity tests) --------------------- */
 /* rtlsdr_ft8d.c:1395-1435: window, 184 FFTs, log-magnitude, quantise.  mag: [nframes][94208] */

@@ -57,13 +57,14 @@ class Ft8GpuError(RuntimeError):
 
 
 ABI_SYMBOLS = [
-    "ft8gpu_create", "ft8gpu_destroy", "ft8gpu_set_stream", "ft8gpu_set_params", "ft8gpu_enable_timing",
+    "ft8gpu_create", "ft8gpu_destroy", "ft8gpu_set_stream", "ft8gpu_get_stream", "ft8gpu_set_params", "ft8gpu_enable_timing",
     "ft8gpu_get_timings", "ft8gpu_synchronize", "ft8gpu_last_error", "ft8gpu_device_count",
     "ft8gpu_decode_batch", "ft8gpu_waterfall", "ft8gpu_find_sync", "ft8gpu_score_map",
     "ft8gpu_decode_candidates", "ft8gpu_collect_spots", "ft8gpu_pack77_std", "ft8gpu_encode",
     "ft8gpu_synth_frames", "ft8gpu_synth_frames_at", "ft8gpu_rx_decimate", "ft8gpu_pskreporter_datagrams", "ft8gpu_format_spots",
     "ft8gpu_dev_alloc", "ft8gpu_dev_free", "ft8gpu_memcpy_h2d", "ft8gpu_memcpy_d2h",
-    "ft8gpu_set_debug_flags", "ft8gpu_selftest_bp_math", "ft8gpu_decode_batch_multi", "ft8gpu_decode_batch_multi_dev",
+    "ft8gpu_set_debug_flags", "ft8gpu_selftest_bp_math", "ft8gpu_gather_spots", "ft8gpu_gather_shutdown",
+    "ft8gpu_shard_workers", "ft8gpu_decode_batch_multi", "ft8gpu_decode_batch_multi_dev",
     "ft8_find_sync", "ft8_decode", "ft8_encode", "pack77",            # ft8_lib level (include/ft8_lib/ft8/*.h)
     "initFFTW", "freeFFTW", "ft8_subsystem", "ft8gpu_read_raw_iq", "ft8gpu_read_c2", "ft8gpu_write_raw_iq",
 ]
@@ -105,6 +106,9 @@ def _declare(L):
     L.ft8gpu_destroy.argtypes = [vp]
     L.ft8gpu_destroy.restype = None
     L.ft8gpu_set_stream.argtypes = [vp, vp]
+    if hasattr(L, "ft8gpu_get_stream"):
+        L.ft8gpu_get_stream.argtypes = [vp]
+        L.ft8gpu_get_stream.restype = vp
     L.ft8gpu_set_params.argtypes = [vp, C.POINTER(Params)]
     L.ft8gpu_enable_timing.argtypes = [vp, C.c_int]
     L.ft8gpu_get_timings.argtypes = [vp, C.POINTER(Timings), C.POINTER(C.c_int32)]
@@ -126,6 +130,9 @@ def _declare(L):
         L.ft8gpu_selftest_bp_math.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.ft8gpu_decode_batch_multi.argtypes = [C.POINTER(vp), C.c_int, vp, C.c_int, vp, vp]
     L.ft8gpu_decode_batch_multi_dev.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp), C.POINTER(C.c_int), vp, vp]
+    if hasattr(L, "ft8gpu_gather_spots"):
+        L.ft8gpu_gather_spots.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, C.POINTER(vp), C.POINTER(vp)]
+        L.ft8gpu_gather_shutdown.restype = None
     L.ft8gpu_rx_decimate.argtypes = [vp, vp, C.c_int, C.c_size_t, vp, C.c_int, C.c_int]
     L.ft8gpu_pskreporter_datagrams.argtypes = [vp, vp, vp, C.c_int, C.POINTER(ReportInfo), vp, vp, vp, C.c_int]
     L.ft8gpu_format_spots.argtypes = [vp, C.c_int32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t]
@@ -221,6 +228,10 @@ class Decoder:
         else:
             h = int(stream_handle) or STREAM_LEGACY
         _check(self.lib.ft8gpu_set_stream(self.h, C.c_void_p(h)))
+
+    def stream_handle(self):
+        """the hipStream_t of the context as an integer (e.g. for torch.cuda.ExternalStream)"""
+        return int(self.lib.ft8gpu_get_stream(self.h) or 0)
 
     def set_debug_flags(self, flags):
         _check(self.lib.ft8gpu_set_debug_flags(self.h, int(flags)))
@@ -400,6 +411,15 @@ def decode_batch_multi_dev(decoders, iq_devs, nframes, decodes=None):
     ns = (C.c_int * k)(*[int(x) for x in nframes])
     _check(load_library().ft8gpu_decode_batch_multi_dev(hs, k, ps, ns, decodes.ctypes.data, n.ctypes.data))
     return decodes, n
+
+
+def gather_spots(decoders, decodes_devs, n_results_devs, frames_per_dev, all_decodes_devs, all_n_results_devs):
+    """ft8gpu_gather_spots: single-process RCCL all-gather of every GPU's device-resident records and counts"""
+    k = len(decoders)
+    arr = lambda xs: (C.c_void_p * k)(*[_ptr(x) for x in xs])
+    hs = (C.c_void_p * k)(*[d.h for d in decoders])
+    _check(load_library().ft8gpu_gather_spots(hs, k, arr(decodes_devs), arr(n_results_devs), int(frames_per_dev),
+                                              arr(all_decodes_devs), arr(all_n_results_devs)))
 
 
 def format_spots(decodes, n_results, dial_freq, year, month, mday, hour, minute):

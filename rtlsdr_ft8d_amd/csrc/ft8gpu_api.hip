@@ -9,6 +9,10 @@
 #include <stdlib.h>
 #include <string.h>
 #include <float.h>
+#include <condition_variable>
+#include <deque>
+#include <dlfcn.h>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <string>
@@ -104,6 +108,7 @@ struct ft8gpu_ctx {
     int slot_form[kTimingSlots]{};         // which form of the pipeline a slot recorded: 0 one launch per stage, 1 two parts
     hipStream_t side = nullptr;            // carries the serial kernels (heap, spots) of one half-batch
                                            // while the main stream works on the other half
+    hipStream_t side2 = nullptr;           // heap replay of part B (beside the one of part A on `side`)
     hipEvent_t dep[6]{};                   // cross-stream dependencies (no timing)
     std::mutex mu;                         // every entry point holds it: concurrent callers of one context serialise
     unsigned debug_flags = 0;              // FT8GPU_DBG_* (test hooks, per context)
@@ -171,7 +176,8 @@ struct StageTimer {
     ft8gpu_ctx *c;
     explicit StageTimer(ft8gpu_ctx *ctx) : c(ctx) {}
     void mark(int i) { if (c->timing) (void)hipEventRecord(c->ev[c->runs % ft8gpu_ctx::kTimingSlots][i], c->stream); }
-    void mark_side(int i) { if (c->timing) (void)hipEventRecord(c->ev[c->runs % ft8gpu_ctx::kTimingSlots][ft8gpu_ctx::kSideEv0 + i], c->side); }
+    void mark_side(int i) { mark_on(c->side, i); }
+    void mark_on(hipStream_t s, int i) { if (c->timing) (void)hipEventRecord(c->ev[c->runs % ft8gpu_ctx::kTimingSlots][ft8gpu_ctx::kSideEv0 + i], s); }
     void done(int form) {
         if (!c->timing) return;
         c->slot_form[c->runs % ft8gpu_ctx::kTimingSlots] = form;
@@ -188,27 +194,33 @@ float elapsed(hipEvent_t a, hipEvent_t b) {
 }
 
 // Large batches: the two serial kernels (exact heap replay, spot collection) keep only one lane per frame
-// busy, so the batch is cut into a SMALL first part A and the rest B, and their serial kernels run on a side
-// stream under the throughput kernels of the other part:
-//   main: waterfall(all) sync(A) sync(B) ..wait heap(A).. decode(A) ..wait heap(B).. decode(B) spots(B)
-//   side:                 heap(A)         heap(B)                     spots(A)
-// heap(A) (a few hundred frames, register form of the replay) hides under sync(B), heap(B) under decode(A),
-// spots(A) under decode(B); what stays exposed is spots(B) and one extra LDPC-kernel tail.  (Measured
-// alternatives, profiles/r02_ab_kernels.json: equal halves with heap(A) under sync(B) or under a per-half
-// waterfall cost 0.1-0.16 ms more; everything in sequence, one launch per stage, costs the heap's 0.24 ms.)
+// busy, so the batch is cut into a SMALL first part A and the rest B, and their serial kernels run on side
+// streams under the throughput kernels of the other part:
+//   main : wf(A) sync(A) wf(B) sync(B) ..wait heap(A).. decode(A) ..wait heap(B).. decode(B) spots(B)
+//   side :            heap(A)                                          spots(A)
+//   side2:                        heap(B)
+// heap(A) hides under the waterfall and sync kernels of B, heap(B) under decode(A), spots(A) under decode(B); what
+// stays exposed is spots(B) and one extra LDPC-kernel tail.  The heap replay is a dependent chain whose length grows
+// with the candidate cap (about 0.1 ms at 120, 0.35 ms at 480) and hardly with the number of frames, so at large caps
+// part A is made big enough for decode(A) to cover heap(B).  (Round 2 ran ONE waterfall launch up front, which left
+// heap(A) only sync(B) to hide under.  Measured alternatives, profiles/r02_ab_kernels.json and r03_ab_pipeline.json:
+// equal halves cost 0.1-0.16 ms more; a K-part pipeline with the waterfall of part k+1 beside the LDPC kernel of part k
+// is SLOWER -- the waterfall's large workgroups are not co-scheduled beside the LDPC kernel's small ones.)
 int run_pipeline_overlapped(ft8gpu_ctx *c, const float *d_iq, int n, struct decoder_results *d_dec, int32_t *d_nres) {
     StageTimer t(c);
     const ft8gpu_params &p = c->params;
     const int mc = p.max_candidates;
     // size of part A in 1/16ths of the batch, whole blocks of 64 frames.  Swept at 4096 frames in one session
-    // (profiles/r02_ab_kernels.json): 1/16 4.99 ms, 2/16 5.03, 4/16 5.03, 8/16 5.22; one launch per stage 5.14; a later
-    // sweep in frames (128 ... 768) stayed within 4.978-4.992 ms: the size is not critical as long as it is small.
-    const int sixteenths = n >= 2048 ? 1 : 2;
+    // (profiles/r02_ab_kernels.json): 1/16 4.99 ms, 2/16 5.03, 4/16 5.03, 8/16 5.22; a later sweep in frames
+    // (128 ... 768) stayed within 4.978-4.992 ms: the size is not critical as long as it is small.
+    int sixteenths = n >= 2048 ? 1 : 2;
+    if (mc > 240) sixteenths *= 2;
     int n0 = ((n * sixteenths / 16) + 63) & ~63;
     if (n0 < 64) n0 = 64;
     if (n0 > n - 64) n0 = n / 2;
     const int n1 = n - n0;
     const size_t lo = (size_t)n0;                                   // frame offset of part B
+    const size_t frame_floats = 2 * (size_t)kNSamples;
     uint8_t *mag1 = c->d_mag + lo * kMagArray;
     uint32_t *lists1 = c->d_lists + lo * kSublistsPerFrame * kSublistCap;
     int32_t *lc1 = c->d_list_counts + lo * kSublistsPerFrame;
@@ -217,28 +229,30 @@ int run_pipeline_overlapped(ft8gpu_ctx *c, const float *d_iq, int n, struct deco
     ft8gpu_decode_status *st1 = c->d_status + lo * mc;
     hipEvent_t *E = c->dep;          // 0: sync(A) done  1: sync(B) done  2: heap(A)  3: heap(B)  4: decode(A)  5: side stream done
 
-    // main stream events: 0 waterfall 1 sync(A) 2 sync(B) 3 | 4 decode(A) 5 decode(B) 6 spots(B) 7 | 8 end
-    // side stream events: 0 heap(A) 1 | 2 heap(B) 3 | 4 spots(A) 5
+    // main stream events: 0 wf(A) 1 sync(A) 2 wf(B) 9 sync(B) 3 | 4 decode(A) 5 decode(B) 6 spots(B) 7 | 8 end
+    // side stream events: 0 heap(A) 1 | 4 spots(A) 5        side2: 2 heap(B) 3
     t.mark(0);
-    HIP_TRY(launch_waterfall(d_iq, c->d_mag, c->d_tab, n, c->num_cus, c->stream));
+    HIP_TRY(launch_waterfall(d_iq, c->d_mag, c->d_tab, n0, c->num_cus, c->stream));
     t.mark(1);
     HIP_TRY(launch_sync(c->d_mag, c->d_lists, c->d_list_counts, nullptr, n0, p.min_score, c->stream));
     HIP_TRY(hipEventRecord(E[0], c->stream));
     t.mark(2);
+    HIP_TRY(launch_waterfall(d_iq + lo * frame_floats, mag1, c->d_tab, n1, c->num_cus, c->stream));
+    t.mark(9);
     HIP_TRY(launch_sync(mag1, lists1, lc1, nullptr, n1, p.min_score, c->stream));
     HIP_TRY(hipEventRecord(E[1], c->stream));
     t.mark(3);
-    // side stream: heap(A), heap(B)
+    // side streams: heap(A), heap(B)
     HIP_TRY(hipStreamWaitEvent(c->side, E[0], 0));
     t.mark_side(0);
     HIP_TRY(launch_heap(c->d_lists, c->d_list_counts, c->d_cands, c->d_counts, n0, mc, c->side));
     t.mark_side(1);
     HIP_TRY(hipEventRecord(E[2], c->side));
-    HIP_TRY(hipStreamWaitEvent(c->side, E[1], 0));
-    t.mark_side(2);
-    HIP_TRY(launch_heap(lists1, lc1, cands1, counts1, n1, mc, c->side));
-    t.mark_side(3);
-    HIP_TRY(hipEventRecord(E[3], c->side));
+    HIP_TRY(hipStreamWaitEvent(c->side2, E[1], 0));
+    t.mark_on(c->side2, 2);
+    HIP_TRY(launch_heap(lists1, lc1, cands1, counts1, n1, mc, c->side2));
+    t.mark_on(c->side2, 3);
+    HIP_TRY(hipEventRecord(E[3], c->side2));
     // main stream: decode(A), decode(B), spots(B)
     HIP_TRY(hipStreamWaitEvent(c->stream, E[2], 0));
     t.mark(4);
@@ -309,6 +323,7 @@ static int create_body(ft8gpu_ctx *c) {
     c->own_stream = true;
     for (auto &slot : c->ev) for (auto &e : slot) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
     for (auto &e : c->dep) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
     for (auto &e : c->copied) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -383,6 +398,7 @@ void ft8gpu_destroy(ft8gpu_ctx *c) {
     for (auto &slot : c->ev) for (auto &e : slot) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->dep) if (e) (void)hipEventDestroy(e);
     if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->side2) { (void)hipStreamSynchronize(c->side2); (void)hipStreamDestroy(c->side2); }
     if (c->copy) (void)hipStreamSynchronize(c->copy);
     for (auto &e : c->copied) if (e) (void)hipEventDestroy(e);
     if (c->copy) (void)hipStreamDestroy(c->copy);
@@ -397,10 +413,17 @@ int ft8gpu_set_stream(ft8gpu_ctx *c, void *hip_stream) {
     CHECK_COMMON(c, 0);
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipStreamSynchronize(c->side));
+    HIP_TRY(hipStreamSynchronize(c->side2));
     if (c->own_stream) { (void)hipStreamDestroy(c->stream); c->own_stream = false; }
     if (hip_stream) c->stream = (hipStream_t)hip_stream;
     else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     return 0;
+}
+
+void *ft8gpu_get_stream(ft8gpu_ctx *c) {
+    if (!c) { fail("ctx is NULL"); return nullptr; }
+    std::lock_guard<std::mutex> lock(c->mu);
+    return (void *)c->stream;
 }
 
 int ft8gpu_set_params(ft8gpu_ctx *c, const ft8gpu_params *p) {
@@ -453,8 +476,8 @@ int ft8gpu_get_timings(ft8gpu_ctx *c, ft8gpu_timings *out, int32_t *nruns) {
             hipEvent_t *sd = e + ft8gpu_ctx::kSideEv0;
             HIP_TRY(hipEventSynchronize(e[8]));
             HIP_TRY(hipEventSynchronize(sd[5]));
-            acc[0] += elapsed(e[0], e[1]);                                   // waterfall
-            acc[1] += elapsed(e[1], e[2]) + elapsed(e[2], e[3]);             // sync: both parts
+            acc[0] += elapsed(e[0], e[1]) + elapsed(e[2], e[9]);             // waterfall: both parts
+            acc[1] += elapsed(e[1], e[2]) + elapsed(e[9], e[3]);             // sync: both parts
             acc[2] += elapsed(sd[0], sd[1]) + elapsed(sd[2], sd[3]);         // heap: both parts (side stream, overlapped)
             acc[3] += elapsed(e[4], e[5]) + elapsed(e[5], e[6]);             // decode: both launches
             acc[4] += elapsed(sd[4], sd[5]) + elapsed(e[6], e[7]);           // spots: A (side, overlapped) + B
@@ -552,6 +575,63 @@ int ft8gpu_decode_batch(ft8gpu_ctx *c, const float *iq, int nframes, struct deco
     return 0;
 }
 
+// Persistent host workers of the multi-GPU entries: one thread per concurrently running shard beyond the caller's
+// own, created on first use and kept for the life of the process (round 2 spawned ndev-1 std::threads per call,
+// which is measurable on small batches).  Workers carry no GPU state of their own: every task enters its context
+// through the usual Entry guard.  No C++ exception crosses the C ABI: a failed thread creation makes post() return
+// false and the caller runs the shard itself.
+class ShardPool {
+public:
+    struct Latch {
+        std::mutex m;
+        std::condition_variable cv;
+        int pending = 0;
+        void wait() { std::unique_lock<std::mutex> l(m); cv.wait(l, [this] { return pending == 0; }); }
+    };
+    static ShardPool &instance() { static ShardPool *p = new ShardPool(); return *p; }    // never destroyed: no join at exit
+    bool post(std::function<void()> fn, Latch *latch) {
+        std::unique_lock<std::mutex> l(m_);
+        try {
+            q_.emplace_back(std::move(fn), latch);
+        } catch (...) { return false; }
+        // one waiting (or starting) worker per queued job, so that shards never queue up behind each other
+        if (idle_ + starting_ < (int)q_.size()) {
+            try { std::thread(&ShardPool::loop, this).detach(); ++workers_; ++starting_; }
+            catch (...) {
+                if (idle_ + starting_ == 0 && workers_ == 0) { q_.pop_back(); return false; }   // nobody would ever run it
+            }
+        }
+        { std::lock_guard<std::mutex> g(latch->m); ++latch->pending; }
+        l.unlock();
+        cv_.notify_one();
+        return true;
+    }
+    int workers() { std::lock_guard<std::mutex> l(m_); return workers_; }
+private:
+    void loop() {
+        bool first = true;
+        for (;;) {
+            std::pair<std::function<void()>, Latch *> job;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                if (first) { --starting_; first = false; }
+                ++idle_;
+                cv_.wait(l, [this] { return !q_.empty(); });
+                --idle_;
+                job = std::move(q_.front());
+                q_.pop_front();
+            }
+            job.first();
+            { std::lock_guard<std::mutex> g(job.second->m); --job.second->pending; }
+            job.second->cv.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<std::pair<std::function<void()>, Latch *>> q_;
+    int workers_ = 0, idle_ = 0, starting_ = 0;
+};
+
 // frames resident on the context's GPU, records to host arrays (used by the multi-GPU entry)
 static int decode_dev_to_host(ft8gpu_ctx *c, const float *d_iq, int nframes, struct decoder_results *decodes, int32_t *n_results) {
     CHECK_COMMON(c, nframes);
@@ -585,16 +665,15 @@ static int run_shards(ft8gpu_ctx *const *ctxs, int ndev, const float *const *iq_
                              : ft8gpu_decode_batch(ctxs[g], iq_of[g], count[g], d, n, FT8GPU_HOST_PTRS);
         if (rc[g]) why[g] = g_err;                       // the error text is thread-local: hand it to the caller's thread
     };
-    std::vector<std::thread> threads;
-    bool spawn_failed = false;
+    // shards 1.. on the persistent workers, shard 0 on the calling thread
+    ShardPool &pool = ShardPool::instance();
+    ShardPool::Latch latch;
     for (int g = 1; g < ndev; ++g) {
         if (count[g] <= 0) continue;
-        try { threads.emplace_back(work, g); }           // no C++ exception may cross the C ABI
-        catch (...) { spawn_failed = true; work(g); }     // no thread to be had: this shard runs on the calling thread
+        if (!pool.post([&work, g] { work(g); }, &latch)) work(g);     // no worker to be had: this shard runs here
     }
-    if (count[0] > 0) work(0);                           // shard 0 on the calling thread
-    for (auto &t : threads) t.join();
-    (void)spawn_failed;
+    if (count[0] > 0) work(0);
+    latch.wait();
     for (int g = 0; g < ndev; ++g)
         if (rc[g]) return fail("shard %d of %d (frames [%d, %d)): %s", g, ndev, first[g], first[g] + count[g], why[g].c_str());
     return 0;
@@ -636,6 +715,122 @@ int ft8gpu_decode_batch_multi_dev(ft8gpu_ctx *const *ctxs, int ndev, const float
     }
     return run_shards(ctxs, ndev, iq_dev, first.data(), count.data(), true, decodes, n_results);
 }
+
+// ---- device-resident gather of the spot list over RCCL (north_star: "a trivial RCCL gather
+// over xGMI for the spot list") for a plain C caller.  ft8gpu_decode_batch_multi[_dev] gather on the HOST, which is
+// what the daemon consumes; this entry leaves the whole job's records in HBM of every GPU (e.g. for
+// ft8gpu_pskreporter_datagrams or a device-side consumer).  Single-process RCCL: one communicator per GPU
+// (ncclCommInitAll), one grouped ncclAllGather per buffer on each context's own stream, so the collective is ordered
+// behind the kernels that produce the records and nothing synchronises the host.
+// librccl is bound at run time (dlopen), not at link time: libft8gpu.so has no RCCL dependency, a process that
+// already mapped an RCCL (PyTorch does) keeps that copy, and a box without RCCL gets a clean error.
+namespace {
+
+typedef struct ncclComm *ncclComm_t;
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string why;
+};
+constexpr int kNcclUint8 = 1;                      // ncclUint8 of rccl.h (ncclInt8 = 0)
+
+Rccl *rccl() {
+    static std::mutex mu;
+    static Rccl *r = nullptr;
+    std::lock_guard<std::mutex> l(mu);
+    if (r && r->lib) return r;
+    if (!r) r = new Rccl();
+    const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    void *h = dlopen(names[0], RTLD_NOW | RTLD_NOLOAD);            // the copy the process already holds, if any
+    for (int i = 0; !h && i < 3; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { const char *e = dlerror(); r->why = e ? e : "dlopen failed"; return r; }
+    r->CommInitAll = (decltype(r->CommInitAll))dlsym(h, "ncclCommInitAll");
+    r->CommDestroy = (decltype(r->CommDestroy))dlsym(h, "ncclCommDestroy");
+    r->AllGather = (decltype(r->AllGather))dlsym(h, "ncclAllGather");
+    r->GroupStart = (decltype(r->GroupStart))dlsym(h, "ncclGroupStart");
+    r->GroupEnd = (decltype(r->GroupEnd))dlsym(h, "ncclGroupEnd");
+    r->GetErrorString = (decltype(r->GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!r->CommInitAll || !r->CommDestroy || !r->AllGather || !r->GroupStart || !r->GroupEnd || !r->GetErrorString) {
+        r->why = "librccl lacks a required nccl* symbol";
+        return r;
+    }
+    r->lib = h;
+    return r;
+}
+
+struct GatherGroup {                                // communicators of one device list, created on first use
+    std::vector<int> devices;
+    std::vector<ncclComm_t> comms;
+};
+std::mutex g_gather_mu;
+std::vector<GatherGroup *> g_groups;
+
+}  // namespace
+
+extern "C" int ft8gpu_gather_spots(ft8gpu_ctx *const *ctxs, int ndev, const struct decoder_results *const *decodes_dev,
+                                   const int32_t *const *n_results_dev, int frames_per_dev,
+                                   struct decoder_results *const *all_decodes_dev, int32_t *const *all_n_results_dev) {
+    if (!ctxs || ndev < 1) return fail("ft8gpu_gather_spots: no contexts");
+    if (!decodes_dev || !n_results_dev || !all_decodes_dev || !all_n_results_dev) return fail("NULL array argument");
+    if (frames_per_dev < 0) return fail("frames_per_dev < 0");
+    if (frames_per_dev == 0) return 0;
+    std::vector<int> devs((size_t)ndev);
+    for (int g = 0; g < ndev; ++g) {
+        if (!ctxs[g]) return fail("ctxs[%d] is NULL", g);
+        if (!decodes_dev[g] || !n_results_dev[g] || !all_decodes_dev[g] || !all_n_results_dev[g]) return fail("NULL buffer for shard %d", g);
+        devs[g] = ctxs[g]->device;
+        for (int h = 0; h < g; ++h)
+            if (devs[h] == devs[g]) return fail("ft8gpu_gather_spots: ctxs[%d] and ctxs[%d] are on the same GPU %d (RCCL needs one rank per device; "
+                                                "several contexts on one GPU gather on the host: ft8gpu_decode_batch_multi_dev)", h, g, devs[g]);
+    }
+    Rccl *r = rccl();
+    if (!r->lib) return fail("RCCL unavailable: %s", r->why.c_str());
+    std::lock_guard<std::mutex> lock(g_gather_mu);
+    GatherGroup *grp = nullptr;
+    for (GatherGroup *c : g_groups) if (c->devices == devs) grp = c;
+    if (!grp) {
+        grp = new (std::nothrow) GatherGroup();
+        if (!grp) return fail("out of host memory");
+        grp->devices = devs;
+        grp->comms.assign((size_t)ndev, nullptr);
+        const int rc = r->CommInitAll(grp->comms.data(), ndev, devs.data());
+        if (rc != 0) { const char *e = r->GetErrorString(rc); delete grp; return fail("ncclCommInitAll failed: %s", e ? e : "?"); }
+        g_groups.push_back(grp);
+    }
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    const size_t rec_bytes = (size_t)frames_per_dev * kMaxMessages * sizeof(struct decoder_results);
+    const size_t cnt_bytes = (size_t)frames_per_dev * sizeof(int32_t);
+    int rc = r->GroupStart();
+    for (int g = 0; g < ndev && rc == 0; ++g) {
+        std::lock_guard<std::mutex> cl(ctxs[g]->mu);
+        (void)hipSetDevice(devs[g]);
+        rc = r->AllGather(decodes_dev[g], all_decodes_dev[g], rec_bytes, kNcclUint8, grp->comms[g], ctxs[g]->stream);
+        if (rc == 0) rc = r->AllGather(n_results_dev[g], all_n_results_dev[g], cnt_bytes, kNcclUint8, grp->comms[g], ctxs[g]->stream);
+    }
+    const int rc_end = r->GroupEnd();
+    if (prev >= 0) (void)hipSetDevice(prev);
+    if (rc == 0) rc = rc_end;
+    if (rc != 0) { const char *e = r->GetErrorString(rc); return fail("RCCL all-gather failed: %s", e ? e : "?"); }
+    return 0;       // enqueued on every context's stream; ft8gpu_synchronize(ctxs[g]) or a later entry of that context waits for it
+}
+
+extern "C" void ft8gpu_gather_shutdown(void) {
+    Rccl *r = rccl();
+    std::lock_guard<std::mutex> lock(g_gather_mu);
+    for (GatherGroup *grp : g_groups) {
+        if (r->lib) for (ncclComm_t c : grp->comms) if (c) (void)r->CommDestroy(c);
+        delete grp;
+    }
+    g_groups.clear();
+}
+
+extern "C" int ft8gpu_shard_workers(void) { return ShardPool::instance().workers(); }
 
 int ft8gpu_waterfall(ft8gpu_ctx *c, const float *iq, int nframes, uint8_t *mag, int flags) {
     CHECK_COMMON(c, nframes);

@@ -158,3 +158,15 @@ def test_product_never_touches_the_oracle():
     assert "oracle" not in out
     sym = subprocess.check_output(["nm", "-D", os.path.join(pkg, "libft8gpu.so")]).decode()
     assert "ft8o_" not in sym
+
+
+def test_gather_entry_argument_errors_and_no_rccl_link_dependency(ft8):
+    """ft8gpu_gather_spots checks its arguments before touching a GPU or RCCL, and libft8gpu.so itself must not
+    depend on librccl (it is bound with dlopen at the first gather, so a plain C caller links without it)"""
+    lib = ft8.load_library()
+    assert lib.ft8gpu_gather_spots(None, 0, None, None, 4, None, None) == -1
+    assert b"no contexts" in lib.ft8gpu_last_error()
+    out = subprocess.check_output(["ldd", os.path.join(ROOT, "rtlsdr_ft8d_amd", "libft8gpu.so")]).decode()
+    assert "rccl" not in out and "nccl" not in out
+    lib.ft8gpu_gather_shutdown()                       # harmless without communicators
+    assert lib.ft8gpu_shard_workers() == 0             # no worker thread until a multi-GPU call needs one

@@ -241,3 +241,51 @@ def test_config4_32768_frames_eight_shards(oracle):
     finally:
         for d in decs:
             d.close()
+
+
+# ---- device-resident gather over RCCL for a C caller --------------------------------------------------
+def test_gather_spots_over_rccl_one_rank_and_refusals():
+    """ft8gpu_gather_spots: single-process RCCL (ncclCommInitAll + grouped ncclAllGather on the context's stream).
+    One GPU per box, so the collective runs with ndev = 1 (RCCL refuses two ranks on one device, and so does the
+    entry, with a message that names the host-gather alternative); the gathered buffers must equal the context's own
+    records, and the stream ordering (decode -> all-gather, no host sync in between) is what the N > 1 path relies on."""
+    import torch
+    import rtlsdr_ft8d_amd as ft8
+    from rtlsdr_ft8d_amd import workload
+    n = 192
+    with ft8.Decoder(device=0, max_frames=n) as d0, ft8.Decoder(device=0, max_frames=n) as d1:
+        iq = _job(ft8, workload, d0, 7, n)
+        spots = torch.zeros((n, 1400), dtype=torch.uint8, device="cuda")
+        nres = torch.zeros((n,), dtype=torch.int32, device="cuda")
+        all_spots = torch.full((n, 1400), 0xEE, dtype=torch.uint8, device="cuda")
+        all_n = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        for _ in range(3):                                           # communicator is created once and reused
+            d0.decode_batch_dev(iq, n, spots, nres)                  # enqueued ...
+            ft8.gather_spots([d0], [spots], [nres], n, [all_spots], [all_n])      # ... and gathered behind it, same stream
+        d0.synchronize()
+        assert int(nres.sum()) > 8 * n
+        assert torch.equal(all_spots, spots) and torch.equal(all_n, nres)
+        with pytest.raises(ft8.Ft8GpuError, match="same GPU"):
+            ft8.gather_spots([d0, d1], [spots, spots], [nres, nres], n, [all_spots, all_spots], [all_n, all_n])
+        with pytest.raises(ft8.Ft8GpuError, match="NULL buffer"):
+            ft8.gather_spots([d0], [0], [nres], n, [all_spots], [all_n])
+    ft8.load_library().ft8gpu_gather_shutdown()
+
+
+def test_multi_entry_keeps_its_worker_threads():
+    """ft8gpu_decode_batch_multi: the host workers are created once and reused (round 2 spawned threads per call)"""
+    import rtlsdr_ft8d_amd as ft8
+    from rtlsdr_ft8d_amd import workload
+    L = ft8.load_library()
+    with ft8.Decoder(device=0, max_frames=32) as a, ft8.Decoder(device=0, max_frames=32) as b, ft8.Decoder(device=0, max_frames=32) as c:
+        host = _job(ft8, workload, a, 0, 96).cpu().numpy()
+        ref, ref_n = a.decode_batch(host)
+        for _ in range(5):
+            got, got_n = ft8.decode_batch_multi([a, b, c], host)
+            assert np.array_equal(got_n, ref_n) and got.tobytes() == ref.tobytes()
+        w = L.ft8gpu_shard_workers()
+        assert 2 <= w <= 8                                           # two shards beside the caller's own; no growth per call
+        for _ in range(5):
+            ft8.decode_batch_multi([a, b, c], host)
+        assert L.ft8gpu_shard_workers() == w

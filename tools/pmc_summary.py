@@ -33,7 +33,7 @@ def csrc_hash():
 KERNELS = ("ft8_decode_kernel", "ft8_waterfall_kernel", "ft8_sync_kernel", "ft8_heap_kernel", "ft8_spots_kernel",
            "ft8_synth_kernel", "ft8_rx_block_kernel")
 WIDE = {"waterfall", "sync", "rx_block"}
-HALF_BATCH = {"sync", "heap", "decode", "spots"}      # two launches per batch (a small first part and the rest): the mean per launch covers half a batch
+HALF_BATCH = {"waterfall", "sync", "heap", "decode", "spots"}      # two launches per batch (a small first part and the rest): the mean per launch covers half a batch
 
 
 def short(name):
@@ -48,7 +48,9 @@ def main():
     ap.add_argument("paths", nargs="+")
     ap.add_argument("--traffic")
     ap.add_argument("--frames", type=int, default=4096)
-    ap.add_argument("--no-overlap", action="store_true", help="counters were collected with FT8GPU_OVERLAP=0")
+    ap.add_argument("--no-overlap", action="store_true", help="counters were collected with FT8GPU_OVERLAP=0 (or a batch below 512 frames): one launch per stage")
+    ap.add_argument("--config-key", default=None, help="store the figures under this key of an EXISTING traffic file (e.g. config4) instead of at its top level")
+    ap.add_argument("--command", default="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-legs")
     args = ap.parse_args()
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for p in args.paths:
@@ -66,7 +68,7 @@ def main():
     if args.traffic:
         t = {"csrc_sha": csrc_hash(),
              "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over "
-                       "`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline`, mean per dispatch; tools/gpu_round.sh + tools/pmc_summary.py"}
+                       f"`{args.command}`, mean per dispatch; tools/gpu_round.sh + tools/pmc_summary.py"}
         for k, v in out.items():
             if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v or k == "synth":
                 continue
@@ -78,6 +80,15 @@ def main():
             if "SQ_ACTIVE_INST_VALU" in v and "GRBM_GUI_ACTIVE" in v:
                 # SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves; GRBM_GUI_ACTIVE is summed over the 8 XCDs
                 t[k]["valu_busy_frac"] = round(v["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * v["GRBM_GUI_ACTIVE"] / 8), 3)
+            for cn in ("SQ_INSTS_VALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
+                if cn in v:
+                    t[k][cn] = v[cn]
+        if args.config_key:
+            whole = json.load(open(args.traffic))
+            if whole.get("csrc_sha") != t["csrc_sha"]:
+                raise SystemExit("the traffic file was collected on other kernel sources")
+            whole[args.config_key] = {k: v for k, v in t.items() if k != "csrc_sha"}
+            t = whole
         json.dump(t, open(args.traffic, "w"), indent=1)
 
 
