@@ -661,6 +661,23 @@ def host_legs(dec, iq, spots, nres, B):
     dec.decode_batch(frames)
     t2 = time.perf_counter()
     out["rx_host_fed_captures_per_s"] = round(ncap / (t2 - t0), 2)
+    # the daemon's operating point: ONE frame per 15 s slot through the drop-in ft8_subsystem (rtlsdr_ft8d.h:164),
+    # host pointers in and out, process-global single-frame context (the median of 50 calls; the first call creates it)
+    one = iq[0].cpu().numpy()
+    i_s, q_s = np.ascontiguousarray(one[0]), np.ascontiguousarray(one[1])
+    import rtlsdr_ft8d_amd as ft8
+    ft8.ft8_subsystem(i_s, q_s)
+    lat = []
+    for _ in range(50):
+        t3 = time.perf_counter()
+        d1, n1 = ft8.ft8_subsystem(i_s, q_s)
+        lat.append(1e3 * (time.perf_counter() - t3))
+    m1 = min(int(n1), ft8.MAX_MESSAGES)
+    ref1 = spots[0].cpu().numpy().view(ft8.RESULT_DTYPE)
+    out["single_frame_ms"] = round(float(np.median(lat)), 4)
+    out["single_frame"] = {"entry": "ft8_subsystem (drop-in, one 15 s frame, host buffers)", "median_ms": round(float(np.median(lat)), 4),
+                           "min_ms": round(min(lat), 4), "max_ms": round(max(lat), 4), "calls": len(lat),
+                           "records_identical_to_batch_run": bool(n1 == int(nres[0].item()) and d1[:m1].tobytes() == ref1[:m1].tobytes())}
     out["rx_host_fed"] = {"captures": ncap, "raw_bytes_per_capture": 2 * npairs, "decimate_ms": round(1e3 * (t1 - t0), 2),
                           "decode_ms": round(1e3 * (t2 - t1), 2), "upload_GBps": round(ncap * 2 * npairs / (t1 - t0) / 1e9, 1)}
     return out

@@ -136,12 +136,31 @@ void ft8o_fft1024_f64(const double *re_in, const double *im_in, double *re, doub
 /* ------------------------------------------------------------------------------------------
  * rtlsdr_ft8d.c:1415-1427 for one bin: log magnitude, scale to 0.5 dB steps, clamp to uint8
  * ---------------------------------------------------------------------------------------- */
+/* Two behaviours, kept apart on purpose:
+ *  - reference-faithful: the statement sequence of :1416, :1425, :1427 exactly as the reference's x86 build executes it.
+ *    For a non-finite or huge db the (int) conversion is undefined behaviour in C; x86's cvttss2si returns INT_MIN
+ *    ("integer indefinite"), which the clamp turns into 0 -- for +inf and NaN alike.
+ *  - fenced (the default of this oracle and the definition the product is tested against): +inf -> 255, NaN -> 0,
+ *    i.e. the saturating conversion of the reference's ARM (Raspberry Pi) targets.  THIS DEVIATES from the x86 build of
+ *    the reference for non-finite |X|^2; it is a fence around undefined behaviour, not a parity claim
+ *    (tests/test_oracle.py::test_quantiser_fence_is_separate_from_the_reference_expression pins the difference).
+ * For every finite db both are the same expression. */
+static int g_quantiser_x86 = 0;
+void ft8o_set_quantiser_x86(int on) { g_quantiser_x86 = on != 0; }
+
+uint8_t ft8o_quantise_x86(float mag2) {
+    float db = 10.0f * log10f(1E-12f + mag2 * 4.0f / (float)((uint32_t)FT8O_NFFT * (uint32_t)FT8O_NFFT));   /* :1416 */
+    const float v = 2 * db + 240;
+    /* (int)v of :1425 where it is defined; INT_MIN where cvttss2si would report "indefinite" (NaN, |v| >= 2^31) */
+    int scaled = (v != v || v >= 2147483648.0f || v < -2147483648.0f) ? (-2147483647 - 1) : (int)v;
+    return (uint8_t)((scaled < 0) ? 0 : ((scaled > 255) ? 255 : scaled));                                     /* :1427 */
+}
+
 uint8_t ft8o_quantise(float mag2) {
+    if (g_quantiser_x86) return ft8o_quantise_x86(mag2);
     /* :1416  NFFT*NFFT is uint32_t 1048576, converted to float for the division */
     float db = 10.0f * log10f(1E-12f + mag2 * 4.0f / (float)((uint32_t)FT8O_NFFT * (uint32_t)FT8O_NFFT));
-    /* Fence: for non-finite |X|^2 (inf / NaN / absurdly large samples) the reference's (int) conversion at
-     * :1425 is undefined behaviour: x86 yields INT_MIN -> 0, ARM (the reference's Raspberry Pi targets)
-     * saturates -> 255 for +inf and 0 for NaN.  Defined here as the saturating result. */
+    /* Fence (see above): non-finite db */
     if (isnan(db)) return 0;
     if (isinf(db)) return (uint8_t)(db > 0 ? 255 : 0);
     int scaled = (int)(2 * db + 240);                                   /* :1425 */

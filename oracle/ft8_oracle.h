@@ -123,7 +123,9 @@ const float *ft8o_twiddles(void);                           /* [1024][2] (cos, -
 
 void ft8o_fft1024(float *re, float *im);                    /* in place; output digit-reversed -> natural */
 void ft8o_fft1024_f64(const double *re_in, const double *im_in, double *re_out, double *im_out);
-uint8_t ft8o_quantise(float mag2);                          /* rtlsdr_ft8d.c:1415-1427 for one bin */
+uint8_t ft8o_quantise(float mag2);                          /* rtlsdr_ft8d.c:1415-1427 for one bin (fenced for non-finite input) */
+uint8_t ft8o_quantise_x86(float mag2);                      /* the same as the reference's x86 build executes it (inf, NaN -> 0) */
+void ft8o_set_quantiser_x86(int on);                        /* ft8o_quantise / ft8o_waterfall follow the x86 form (default: fenced) */
 void ft8o_waterfall(const float *iSamples, const float *qSamples, uint8_t *mag_power);
 void ft8o_waterfall_f64(const float *iSamples, const float *qSamples, uint8_t *mag_power);
 

@@ -160,6 +160,10 @@ bool ft8_decode(const waterfall_t *power, const candidate_t *cand, message_t *me
     pthread_mutex_lock(&g_lock);
     if (global_ctx_init() == 0) {
         int idx = -1;
+        /* The remembered list answers only for the very bytes ft8_find_sync() saw: the checksum (94 KB, about 10 us) is
+         * taken on EVERY call, so a caller that rewrites the waterfall in place, or reuses the address for another one
+         * without a new ft8_find_sync(), gets a fresh single-candidate decode instead of stale statuses. */
+        if (g_l2.mag == power->mag && waterfall_checksum(power->mag) != g_l2.mag_sum) g_l2.mag = NULL;
         if (g_l2.mag == power->mag)
             for (int i = 0; i < g_l2.ncand; i++)
                 if (!memcmp(&g_l2.cands[i], cand, sizeof *cand)) { idx = i; break; }
@@ -167,8 +171,7 @@ bool ft8_decode(const waterfall_t *power, const candidate_t *cand, message_t *me
             /* first ft8_decode() of this list (or another iteration count): one launch for all candidates */
             const ft8gpu_params p = { g_l2.min_score, g_l2.cap, max_iterations };
             const int32_t n = g_l2.ncand;
-            if (waterfall_checksum(power->mag) != g_l2.mag_sum) idx = -1;        /* the bytes changed since ft8_find_sync() */
-            else if (ft8gpu_set_params(g_ctx, &p) != 0 ||
+            if (ft8gpu_set_params(g_ctx, &p) != 0 ||
                      ft8gpu_decode_candidates(g_ctx, power->mag, g_l2.cands, &n, 1, g_l2.st, FT8GPU_HOST_PTRS) != 0) {
                 fprintf(stderr, "ft8gpu: ft8_decode failed: %s\n", ft8gpu_last_error());
                 idx = -2;
@@ -206,8 +209,8 @@ bool ft8_decode(const waterfall_t *power, const candidate_t *cand, message_t *me
 int pack77(const char *msg, uint8_t *c77) {
     uint8_t p[10];
     if (ft8gpu_pack77_std(msg, p) != 0) return -1;
-    memcpy(c77, p, 10);
-    c77[10] = c77[11] = 0;                                 /* FTX_LDPC_K_BYTES = 12 */
+    memcpy(c77, p, 10);                                    /* the 77-bit payload: 10 bytes, as upstream's pack77 fills (a caller may
+                                                              pass uint8_t[10]); ft8_encode reads no further */
     return 0;
 }
 

@@ -276,6 +276,9 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
                 const c32 y1 = add_mul_mi(t1, t3);
                 quantise2(y0, y1, s_thr, q0[i], q1[i]);
             }
+            // ob aliases the front of xb (float4 loads above, 16-bit stores below, different types): make the order
+            // "every lane's stage-4 loads, then the stores" explicit instead of leaving it to the schedule
+            wave_lds_sync();
             // bins k0..k0+3 -> [freq_sub = k&1][pos = k>>1]  (rtlsdr_ft8d.c:1420-1428)
             const int k0 = 64 * (lane & 3) + 16 * ((lane >> 2) & 3) + 4 * (lane >> 4);
             const int h = k0 >> 1;

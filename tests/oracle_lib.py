@@ -65,6 +65,10 @@ def lib():
     L.ft8o_fft1024.argtypes = [fp, fp]
     L.ft8o_quantise.argtypes = [C.c_float]
     L.ft8o_quantise.restype = C.c_uint8
+    L.ft8o_quantise_x86.argtypes = [C.c_float]
+    L.ft8o_quantise_x86.restype = C.c_uint8
+    L.ft8o_set_quantiser_x86.argtypes = [C.c_int]
+    L.ft8o_set_quantiser_x86.restype = None
     L.ft8o_waterfall.argtypes = [fp, fp, u8p]
     L.ft8o_waterfall_f64.argtypes = [fp, fp, u8p]
     L.ft8o_find_sync.argtypes = [u8p, C.c_int, C.c_void_p, C.c_int]

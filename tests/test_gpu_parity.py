@@ -58,7 +58,9 @@ def test_waterfall_bit_exact(oracle, gpu_decoder, frames, oracle_mags):
 def test_waterfall_nonfinite_and_overflowing_samples(oracle, gpu_decoder):
     """inf, NaN and FLT_MAX samples: |X|^2 overflows or is NaN.  The reference's (int) conversion is
     undefined there; the fence (oracle ft8o_quantise) is 255 for +inf and 0 for NaN, and a
-    saturated cell must not leak into its neighbour (the packed 16-bit store of the kernel)."""
+    saturated cell must not leak into its neighbour (the packed 16-bit store of the kernel).
+    NOT a parity claim: the reference as built on x86 yields 0 for +inf (ft8o_quantise_x86); this test pins the
+    product to the fenced definition, and tests/test_oracle.py pins how the two definitions differ."""
     rng = np.random.default_rng(7)
     fmax = np.finfo(np.float32).max
     frames = []
@@ -620,8 +622,11 @@ def test_ft8_lib_level_symbols_match_the_oracle(oracle, frames, oracle_mags):
         other = heap[:1].copy()                              # a candidate ft8_find_sync never returned
         other["freq_offset"] += 1
         check(mag, other, 20)
-        mag[1000:60000] = np.random.default_rng(k).integers(0, 255, 59000, dtype=np.uint8)   # same buffer, new bytes
-        for c in (0, 1, n - 1):
+        for c in range(n):                                   # back to 20: the list is decoded again and fully cached ...
+            check(mag, heap[c:c + 1], 20)
+        mag[1000:60000] = np.random.default_rng(k).integers(0, 255, 59000, dtype=np.uint8)   # ... same buffer, new bytes:
+        for c in (0, 1, n - 1):                              # a cached answer would be stale now, also at the cached iteration count
+            check(mag, heap[c:c + 1], 20)
             check(mag, heap[c:c + 1], 7)
     assert nok > 30
     # geometry the kernels are not built for is refused

@@ -192,6 +192,39 @@ def test_quantiser_truncation_and_clamp(oracle):
     assert q(float("inf")) == 255 and q(3.0e38) == 255 and q(float("nan")) == 0
 
 
+def test_quantiser_fence_is_separate_from_the_reference_expression(oracle):
+    """The oracle keeps two quantisers apart: ft8o_quantise_x86 is rtlsdr_ft8d.c:1416-1427 as the reference's x86
+    build executes it ((int) of a non-finite value = INT_MIN -> 0), ft8o_quantise is the FENCED definition the
+    product is tested against (+inf -> 255, NaN -> 0: the saturating conversion of the reference's ARM targets).
+    They are the same function for every finite value -- checked here on a dense sweep and at every threshold -- and
+    differ exactly where the reference's behaviour is undefined: the product's answer for +inf / overflowing |X|^2
+    is a documented deviation from the x86 reference build, not a parity claim."""
+    L = oracle.lib()
+    q, qx = L.ft8o_quantise, L.ft8o_quantise_x86
+    rng = np.random.default_rng(11)
+    vals = np.concatenate([10.0 ** rng.uniform(-25, 37, 200000), [0.0, 1e-45, 1.17e-38, 3.0e38]]).astype(np.float32)
+    assert all(q(float(v)) == qx(float(v)) for v in vals[::7])          # finite: one function
+    for k in range(1, 256):                                             # and around every step of the staircase
+        y = np.float32(10.0 ** ((k - 240) / 20.0)) * np.float32(2 ** 18)
+        for v in (np.nextafter(y, np.float32(0)), y, np.nextafter(y, np.float32(np.inf))):
+            assert q(float(v)) == qx(float(v))
+    inf, nan = float("inf"), float("nan")
+    assert (q(inf), qx(inf)) == (255, 0)                                # the deviation, stated
+    assert (q(nan), qx(nan)) == (0, 0)
+    # the switch routes the whole waterfall through the x86 form (and back)
+    iq = rng.normal(0, 0.1, (2, 48000)).astype(np.float32)
+    iq[0, 5000] = np.inf
+    fenced = oracle.waterfall(iq[0], iq[1])
+    L.ft8o_set_quantiser_x86(1)
+    try:
+        x86 = oracle.waterfall(iq[0], iq[1])
+    finally:
+        L.ft8o_set_quantiser_x86(0)
+    assert np.array_equal(fenced, oracle.waterfall(iq[0], iq[1]))
+    hit = fenced != x86
+    assert hit.any() and set(np.unique(fenced[hit])) <= {255} and set(np.unique(x86[hit])) <= {0}
+
+
 # ---- sync search ------------------------------------------------------------------------------------
 def test_find_sync_heap_semantics(oracle):
     """the retained multiset is the top-N of all scores >= min_score and comes out sorted"""

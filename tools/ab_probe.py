@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """A/B of pipeline variants in ONE process and GPU session (boxes differ by several percent, so arms of an
 experiment must share a box): the bench batch decoded under different FT8GPU_DBG_* flag sets, interleaved.
-  python tools/ab_probe.py [--frames 4096] [--steps 20] [--rounds 3] --arms 0 8 16 24"""
+  python tools/ab_probe.py [--frames 4096] [--steps 20] [--rounds 3] --arms 0 4
+The arms are sums of the FT8GPU_DBG_* bits of include/ft8gpu.h (1 IEEE division, 2 pipeline form of the stage entry,
+4 one launch per stage); unknown bits are refused by ft8gpu_set_debug_flags.  (The arms 8 / 16 / 24 quoted in
+profiles/r02_ab_kernels.json selected experimental kernels of builds that no longer exist; two BUILDS are compared
+with tools/ab_libs.py.)"""
 import argparse
 import hashlib
 import json
