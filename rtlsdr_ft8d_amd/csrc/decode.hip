@@ -61,6 +61,7 @@ struct DecodeTables {
     uint8_t  row_valid[2][64];
     uint8_t  row_seven[2][64];        // row has 7 members (else 6: slot 6 must stay 1.0f)
     uint64_t group_mask[kMaxCheckGroups + 1][kMaxCheckGroups][3];   // [G][g]: XOR of the row masks of check rows m with m % G == g
+    uint16_t crc_bit[77];             // CRC-14 (over 82 bits) of the message whose only set bit is payload bit i
 };
 
 __device__ DecodeTables d_tab;
@@ -121,9 +122,24 @@ __device__ __forceinline__ int wave_sum(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// the same reduction with XOR (CRC contributions of the set payload bits)
+__device__ __forceinline__ uint32_t wave_xor(uint32_t x) {
+    int v = (int)x;
+    v ^= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+    v ^= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+    v ^= __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+    v ^= __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
+    v ^= __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);
+    v ^= __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);
+    return (uint32_t)__builtin_amdgcn_readlane(v, 63);
+}
+
 // ftx_compute_crc(a91 with bits 77.. cleared, 82 bits): CRC-14, polynomial 0x2757.  Bit-serial
-// restatement (only the first 77 bits can be set; five zero bits follow).
-__device__ inline uint32_t crc14_82(const uint8_t *msg) {
+// restatement (only the first 77 bits can be set; five zero bits follow).  Runs on the host when the tables are
+// built: the kernel uses the linearity of the CRC (init 0, no final XOR) -- the CRC of a message is the XOR of the
+// CRCs of its set bits -- so each lane contributes the table entries of the payload bits it holds and one DPP
+// reduction replaces 82 dependent shift/xor steps on a single lane.
+__host__ __device__ inline uint32_t crc14_82(const uint8_t *msg) {
     uint32_t rem = 0;
     int idx_byte = 0;
     for (int bit = 0; bit < 82; ++bit) {
@@ -464,7 +480,14 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
         // (the next iteration's toc stores hit only this lane's own slots; LDS is in order per wave)
     }
 
-    // ---- pack_bits / CRC / unpack77 (one lane) -----------------------------------------------
+    // ---- pack_bits / CRC / unpack77 -----------------------------------------------------------
+    // codeword bit i is bit (i & 63) of B{i >> 6}: lane l holds payload bits l and (for l < 13) 64 + l
+    uint32_t crc_calc = 0;
+    if (min_errors == 0) {                                       // wave-uniform
+        uint32_t c = ((B0 >> lane) & 1ull) ? d_tab.crc_bit[lane] : 0u;
+        if (lane < 13 && ((B1 >> lane) & 1ull)) c ^= d_tab.crc_bit[64 + lane];
+        crc_calc = wave_xor(c);
+    }
     if (lane == 0) {
         ft8gpu_decode_status st;
         st.ldpc_errors = (int16_t)min_errors;
@@ -490,7 +513,7 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
             a91[9] &= 0xF8;
             a91[10] = 0;
             a91[11] = 0;
-            st.crc_calculated = (uint16_t)crc14_82(a91);
+            st.crc_calculated = (uint16_t)crc_calc;
             if (st.crc_extracted == st.crc_calculated) {
                 const int rc = ft8dev::unpack77(a91, st.text);
                 st.unpack_status = (int8_t)rc;
@@ -544,6 +567,11 @@ hipError_t decode_tables_init(hipStream_t s) {
                 const int n = kFT8_Nm[m][j] - 1;
                 h.group_mask[G][m % G][n >> 6] ^= 1ull << (n & 63);
             }
+    }
+    for (int i = 0; i < 77; ++i) {
+        uint8_t m[12] = { 0 };
+        m[i >> 3] = (uint8_t)(0x80u >> (i & 7));                 // payload bit i, MSB first (pack_bits order)
+        h.crc_bit[i] = (uint16_t)crc14_82(m);
     }
     return hipMemcpyToSymbolAsync(HIP_SYMBOL(d_tab), &h, sizeof(h), 0, hipMemcpyHostToDevice, s);
 }

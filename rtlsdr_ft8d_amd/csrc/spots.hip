@@ -129,18 +129,24 @@ void ft8_spots_kernel(const ft8gpu_candidate *__restrict__ cands, const int32_t 
         }
         wave_lds_sync();
 
-        // :1487-1503 -- is the message already known?  Against the kept messages, then against the
-        // earlier live lanes of this chunk (both loops have wave-uniform trip counts).
+        // :1487-1503 -- is the message already known?  First against the messages kept from earlier chunks.
         bool dup = false;
         for (int t = 0; t < num_decoded; ++t)
             if (ok && L.thash[t] == my_hash && text_equal(L.ttext[t], L.ctext[lane])) dup = true;
-        for (unsigned long long m = live; m != 0ull; m &= m - 1) {
-            const int j = __builtin_ctzll(m);                                 // wave-uniform
-            if (ok && j < lane && L.chash[j] == my_hash && text_equal(L.ctext[j], L.ctext[lane])) dup = true;
+        // Then inside the chunk, leader by leader: the first lane that is still undecided cannot have an equal
+        // message before it (that one would be a leader, and would have struck it), so it is NEW; it strikes every
+        // later lane carrying its message.  One round per UNIQUE message of the chunk (about a dozen) instead of
+        // one per decoded candidate (about forty), and a text comparison only where the 16-bit hashes agree.
+        unsigned long long pending = __ballot(ok && !dup), fresh = 0ull;
+        while (pending != 0ull) {                                             // wave-uniform
+            const int j = __builtin_ctzll(pending);
+            fresh |= 1ull << j;
+            const bool same = ok && !dup && lane > j && L.chash[j] == my_hash && text_equal(L.ctext[j], L.ctext[lane]);
+            dup = dup || same;
+            pending &= ~((1ull << j) | __ballot(same));
         }
-        const unsigned long long fresh = __ballot(ok && !dup);
         const int rank = num_decoded + __popcll(fresh & below);               // position among the frame's unique messages
-        const bool keep = ok && !dup && rank < kMaxMessages;                  // table full: drop (the reference never terminates there)
+        const bool keep = ((fresh >> lane) & 1ull) != 0ull && rank < kMaxMessages;                  // table full: drop (the reference never terminates there)
         if (keep) {                                                           // :1505-1520
 #pragma unroll
             for (int k = 0; k < kTextDw; ++k) L.ttext[rank][k] = L.ctext[lane][k];
