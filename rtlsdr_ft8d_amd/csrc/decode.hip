@@ -59,7 +59,8 @@ struct DecodeTables {
     uint16_t edge_slot[3][64][3];     // [r][lane][m_idx] -> float index of slot (m, pos) in the LDS tile
     uint64_t rowmask[2][64][3];       // [rr][lane][word] bit mask of the variables of check m = lane + 64 rr
     uint8_t  row_valid[2][64];
-    uint8_t  row_seven[2][64];        // row has 7 members (else 6: slot 6 must stay 1.0f)
+    uint8_t  own6[64], own7[64];      // product ownership: lane l computes the products of 6-member row own6[l] (59 rows) and of
+                                      // 7-member row own7[l] (24 rows); kRows - 1 (the spare row) = none
     uint64_t group_mask[kMaxCheckGroups + 1][kMaxCheckGroups][3];   // [G][g]: XOR of the row masks of check rows m with m % G == g
     uint16_t crc_bit[77];             // CRC-14 (over 82 bits) of the message whose only set bit is payload bit i
 };
@@ -242,13 +243,10 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
             for (int w = 0; w < 3; ++w) gmask[g][w] = d_tab.group_mask[kCheckGroups][g][w];      // wave-uniform: scalar loads
     }
     uint64_t rmask[2][3];
-    bool rvalid[2], rseven[2];
-    int rowidx[2];
+    bool rvalid[2];
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         rvalid[rr] = d_tab.row_valid[rr][lane] != 0;
-        rseven[rr] = d_tab.row_seven[rr][lane] != 0;
-        rowidx[rr] = rvalid[rr] ? lane + 64 * rr : kRows - 1;
         // the row masks are only needed by the exact check: the counting form uses them every iteration and
         // keeps them in registers; the pipeline form runs that check on about one iteration in eight and
         // fetches them from the (cache-resident) table then, which frees 12 VGPRs -- one more wave per SIMD
@@ -256,16 +254,14 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
         for (int w = 0; w < 3; ++w) rmask[rr][w] = COUNT_ERRORS ? d_tab.rowmask[rr][lane][w] : 0ull;
     }
 
-    // check-row tile: the 7th slot of a 6-member row is never written by an edge and must read 1.0f
-    // from the first iteration on (afterwards the row owner rewrites it every iteration); the spare
-    // row only needs finite content
-    {
-        float *hiz0 = reinterpret_cast<float *>(planeHI + rowidx[0]) + 2, *hiz1 = reinterpret_cast<float *>(planeHI + rowidx[1]) + 2;
-        *hiz0 = 1.0f;
-        *hiz1 = 1.0f;
-        if (lane < 8) toc[slot_index(kRows - 1, lane)] = 1.0f;
-        wave_lds_sync();
-    }
+    // Ownership of the check-row products.  24 rows have seven members and 59 have six; a lane computes one row of
+    // each kind with a program of exactly that length (25 and 18 multiplications) instead of two passes of the
+    // seven-member program in which a six-member row multiplies by a stored 1.0f six times.
+    const int row6 = d_tab.own6[lane], row7 = d_tab.own7[lane];
+    const bool has6 = row6 != kRows - 1, has7 = row7 != kRows - 1;
+    // the spare row only needs finite content (idle lanes of the variable side read and write it)
+    if (lane < 8) toc[slot_index(kRows - 1, lane)] = 1.0f;
+    wave_lds_sync();
 
     // ---- bp_decode ---------------------------------------------------------------------------
     // Half domain.  The reference adds tov = -2*atanh(.) to the LLR and then forms x = -Tnm/2.  Scaling
@@ -429,23 +425,34 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
         wave_lds_sync();
 
         // ---- check rows: ordered products that skip one member, for all members ---------------
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            if (rr == 1 && !rvalid[1]) continue;                              // 45 of 64 lanes own no second row (EXEC mask)
-            const float4 lo = planeLO[rowidx[rr]], hi = planeHI[rowidx[rr]];
+        // o_k = product of the row's other members in row order: the prefixes p_k = v0 * ... * v(k-1) are shared, every
+        // o_k then continues its own chain (a shared suffix would change the association, i.e. the roundings).  Chains of
+        // equal length run as packed pairs: (o0, o1), (o2, o3) from (p2 * v3, p3), (o4, o5).
+        if (has6) {                                                           // 59 lanes (EXEC mask)
+            const float4 lo = planeLO[row6], hi = planeHI[row6];
+            const float v0 = lo.x, v1 = lo.y, v2 = lo.z, v3 = lo.w, v4 = hi.x, v5 = hi.y;
+            const f2 o01 = (((f2{ v1, v0 } * v2) * v3) * v4) * v5;           // skip 0 | skip 1
+            const float p2 = v0 * v1;
+            const float p3 = p2 * v2;
+            const float p4 = p3 * v3;
+            const f2 o23 = (f2{ p2 * v3, p3 } * v4) * v5;                     // skip 2 | skip 3
+            const float o4 = p4 * v5, o5 = p4 * v4;
+            planeLO[row6] = make_float4(o01.x, o01.y, o23.x, o23.y);
+            *reinterpret_cast<float2 *>(planeHI + row6) = make_float2(o4, o5);
+        }
+        if (has7) {                                                           // 24 lanes
+            const float4 lo = planeLO[row7], hi = planeHI[row7];
             const float v0 = lo.x, v1 = lo.y, v2 = lo.z, v3 = lo.w, v4 = hi.x, v5 = hi.y, v6 = hi.z;
-            const f2 o01 = ((((f2{ v1, v0 } * v2) * v3) * v4) * v5) * v6;   // skip 0 | skip 1
+            const f2 o01 = ((((f2{ v1, v0 } * v2) * v3) * v4) * v5) * v6;
             const float p2 = v0 * v1;
             const float p3 = p2 * v2;
             const float p4 = p3 * v3;
             const float p5 = p4 * v4;
-            const float o2 = (((p2 * v3) * v4) * v5) * v6;
-            const float o3 = ((p3 * v4) * v5) * v6;
-            const float o4 = (p4 * v5) * v6;
-            const float o5 = p5 * v6;
-            const float o6 = rseven[rr] ? p5 * v5 : 1.0f;                    // 6-member rows keep 1.0f in slot 6
-            planeLO[rowidx[rr]] = make_float4(o01.x, o01.y, o2, o3);
-            planeHI[rowidx[rr]] = make_float4(o4, o5, o6, 1.0f);
+            const f2 o23 = ((f2{ p2 * v3, p3 } * v4) * v5) * v6;
+            const f2 o45 = f2{ p4 * v5, p5 } * v6;                            // skip 4 | skip 5
+            const float o6 = p5 * v5;
+            planeLO[row7] = make_float4(o01.x, o01.y, o23.x, o23.y);
+            planeHI[row7] = make_float4(o45.x, o45.y, o6, 1.0f);
         }
         wave_lds_sync();
 
@@ -551,7 +558,6 @@ hipError_t decode_tables_init(hipStream_t s) {
         for (int l = 0; l < 64; ++l) {
             const int m = l + 64 * rr;
             h.row_valid[rr][l] = m < kLdpcM;
-            h.row_seven[rr][l] = (m < kLdpcM) ? (kFT8_Num_rows[m] == 7) : 1;
             h.rowmask[rr][l][0] = h.rowmask[rr][l][1] = h.rowmask[rr][l][2] = 0;
             if (m >= kLdpcM) continue;
             for (int j = 0; j < kFT8_Num_rows[m]; ++j) {
@@ -559,6 +565,14 @@ hipError_t decode_tables_init(hipStream_t s) {
                 h.rowmask[rr][l][n >> 6] |= 1ull << (n & 63);
             }
         }
+    {
+        int n6 = 0, n7 = 0;
+        for (int l = 0; l < 64; ++l) h.own6[l] = h.own7[l] = (uint8_t)(kRows - 1);
+        for (int m = 0; m < kLdpcM; ++m) {
+            if (kFT8_Num_rows[m] == 7) { if (n7 >= 64) abort(); h.own7[n7++] = (uint8_t)m; }
+            else { if (n6 >= 64) abort(); h.own6[n6++] = (uint8_t)m; }
+        }
+    }
     for (int G = 1; G <= kMaxCheckGroups; ++G) {
         for (int g = 0; g < kMaxCheckGroups; ++g)
             for (int w = 0; w < 3; ++w) h.group_mask[G][g][w] = 0;

@@ -115,6 +115,19 @@ def main():
         if hdr:
             per_loop[hdr] = per_loop.get(hdr, 0) + len(ops)
     loop = max(per_loop, key=per_loop.get)
+    # straight-line cost outside the loop: everything before the loop header (candidate fetch, LLR, normalisation,
+    # table loads) and the part of the epilogue every candidate runs (status record; CRC / unpack77 only for codewords)
+    first_loop = next(i for i, b in enumerate(blocks) if b[1] == loop)
+    last_loop = max(i for i, b in enumerate(blocks) if b[1] == loop)
+    def count(bs):
+        c = {}
+        for _, _, ops, _ in bs:
+            for op in ops:
+                k = classify(op)
+                c[k] = c.get(k, 0) + 1
+        return c
+    prologue = count(blocks[:first_loop])
+    epilogue_all = count(blocks[last_loop + 1:])
     rows = []
     for lab, hdr, ops, text in blocks:
         if hdr != loop:
@@ -168,6 +181,9 @@ def main():
     out = {"kernel": args.kernel, "loop_header": loop, "blocks": rows,
            "fast_stream": fast, "ieee_stream": total(("ieee", "ieee*")), "common_blocks": common, "rarely_executed_on_the_fast_path": rare,
            "per_iteration_fast_path": per_iter,
+           "prologue_straight_line": prologue,
+           "epilogue_all_paths_static": epilogue_all,
+           "prologue_valu_issue_slots": round(prologue.get("valu", 0) + args.pk_cost * prologue.get("valu_pk", 0) + args.trans_cost * prologue.get("trans", 0), 1),
            "valu_issue_slots_per_iteration": round(slots, 1),
            "slot_costs": {"valu": 1.0, "valu_pk": args.pk_cost, "trans": round(args.trans_cost, 3),
                           "note": "one slot = one v_mul_f32 (wave64); SALU, LDS and waits issue from other ports; three-operand VOP3 "
