@@ -18,6 +18,7 @@
 //   * arithmetic order of the FFT is the "R4DIF-1024" order documented in DESIGN.md; compiled with
 //     -ffp-contract=off so every float operation is a single IEEE operation.
 #include "ft8gpu_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -296,6 +297,132 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
     }
 }
 
+
+// ---- second form of the kernel: four workgroups per CU ----------------------------------------------------------------
+// The form above stages a work item's 1792 samples in LDS (14 KB beside 35 KB of exchange buffers: three workgroups per
+// CU) and keeps 76 per-lane constants in registers (160 VGPRs: three waves per SIMD).  Here every wave reads the 1024
+// samples of its row straight from global memory -- 32 coalesced 256-byte loads; the four waves of a workgroup take
+// four consecutive rows, whose 75 % overlap is served by the CU's vector L1 -- so there is no staging buffer, no
+// __syncthreads() and no prefetch registers, and the twiddles of stages 1-3 (multiples of 4: a 256-entry table, 2 KB
+// of LDS) are fetched where they are used instead of living in 36 VGPRs.  38 KB of LDS and at most 128 VGPRs:
+// four workgroups per CU, four waves per SIMD.  Same butterflies in the same order: bit-identical output.
+__device__ __forceinline__ void bfly_stage_a(c32 (&x)[16], int a, float2 w1, float2 w2, float2 w3) {
+    bfly4(x[a], x[a + 4], x[a + 8], x[a + 12]);
+    x[a + 4]  = cmul(x[a + 4],  w1);
+    x[a + 8]  = cmul(x[a + 8],  w2);
+    x[a + 12] = cmul(x[a + 12], w3);
+}
+__device__ __forceinline__ void bfly_stage_b(c32 (&x)[16], int q, float2 w1, float2 w2, float2 w3) {
+    bfly4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+    x[4 * q + 1] = cmul(x[4 * q + 1], w1);
+    x[4 * q + 2] = cmul(x[4 * q + 2], w2);
+    x[4 * q + 3] = cmul(x[4 * q + 3], w3);
+}
+
+__global__ __launch_bounds__(256, 4)
+void ft8_waterfall_kernel_v2(const float *__restrict__ iq, uint8_t *__restrict__ mag,
+                             const Ft8Tables *__restrict__ tab, int nitems, int nframes, int xcd_order) {
+    __shared__ __attribute__((aligned(16))) float2 s_x[4][kXbuf];            // per-wave exchange
+    __shared__ __attribute__((aligned(16))) float2 s_tw4[256];               // tw[4 k]
+    __shared__ __attribute__((aligned(16))) float s_thr[260];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 260; i += 256) s_thr[i] = tab->qthr[i];
+    s_tw4[tid] = tab->tw[4 * tid];
+
+    float hw[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) hw[a] = tab->hann[lane + 64 * a];
+    float2 twA1[4][3];                                                       // stage 0: L = 1024, every index occurs
+    const int j2 = lane & 3, b16 = lane >> 2;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 1; q < 4; ++q) twA1[a][q - 1] = tab->tw[(q * (lane + 64 * a)) & 1023];
+    __syncthreads();                                                         // tables are in place (the only barrier)
+
+    float2 *xb = s_x[wave];
+    unsigned char *ob = reinterpret_cast<unsigned char *>(xb);
+    int wbase2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wbase2[r] = 32 * b16 + 2 * kHalfUnits * (j2 >> 1) + (j2 & 1) + 2 * (r ^ (b16 & 3));
+    const int rbase2 = 2 * (lane ^ ((lane >> 4) & 3));
+
+    int step = 0;
+    int item = xcd_order ? xcd_item(0, nframes) : ((int)blockIdx.x < nitems ? (int)blockIdx.x : -1);
+    while (item >= 0) {
+        const int frame = item / kWfItemsPerFrame;
+        const int chunk = item - frame * kWfItemsPerFrame;
+        const int row = chunk * kWfRowsPerItem + wave;                       // = 2*idx_block + time_sub
+        const float *pI = iq + (size_t)frame * (2 * kNSamples) + row * 256 + lane;
+        const float *pQ = pI + kNSamples;
+
+        c32 x[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) x[a] = c32{ pI[64 * a], pQ[64 * a] };   // rtlsdr_ft8d.c:1407-1410
+#pragma unroll
+        for (int a = 0; a < 16; ++a) x[a] = x[a] * c32{ hw[a], hw[a] };
+        // stages 0, 1
+#pragma unroll
+        for (int a = 0; a < 4; ++a) bfly_stage_a(x, a, twA1[a][0], twA1[a][1], twA1[a][2]);
+        {
+            const float2 w1 = s_tw4[lane], w2 = s_tw4[(2 * lane) & 255], w3 = s_tw4[(3 * lane) & 255];   // tw[4 q lane]
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bfly_stage_b(x, q, w1, w2, w3);
+        }
+#pragma unroll
+        for (int a = 0; a < 16; ++a) xb[pad_idx(lane + 64 * a)] = make_float2(x[a].x, x[a].y);
+        wave_lds_sync();
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            const float2 v = xb[pad_idx(64 * b16 + j2 + 4 * a)];
+            x[a] = c32{ v.x, v.y };
+        }
+        // stages 2, 3
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int jj = j2 + 4 * a;                                       // tw[16 q jj] = tw4[4 q jj]
+            bfly_stage_a(x, a, s_tw4[(4 * jj) & 255], s_tw4[(8 * jj) & 255], s_tw4[(12 * jj) & 255]);
+        }
+        {
+            const float2 w1 = s_tw4[(16 * j2) & 255], w2 = s_tw4[(32 * j2) & 255], w3 = s_tw4[(48 * j2) & 255];   // tw[64 q j2]
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bfly_stage_b(x, q, w1, w2, w3);
+        }
+#pragma unroll
+        for (int a = 0; a < 16; ++a) xb[wbase2[a & 3] + 8 * (a >> 2)] = make_float2(x[a].x, x[a].y);
+        wave_lds_sync();
+
+        unsigned q0[4], q1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 *src = reinterpret_cast<const float4 *>(xb + rbase2 + 128 * i);
+            const float4 v01 = src[0], v23 = src[kHalfUnits];
+            const c32 a0 = { v01.x, v01.y }, a1 = { v01.z, v01.w }, a2 = { v23.x, v23.y }, a3 = { v23.z, v23.w };
+            const c32 t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = a1 - a3;
+            const c32 y0 = t0 + t2;
+            const c32 y1 = add_mul_mi(t1, t3);
+            quantise2(y0, y1, s_thr, q0[i], q1[i]);
+        }
+        wave_lds_sync();                            // every lane's stage-4 loads before the stores into the same bytes
+        const int k0 = 64 * (lane & 3) + 16 * ((lane >> 2) & 3) + 4 * (lane >> 4);
+        const int h = k0 >> 1;
+        *reinterpret_cast<unsigned short *>(ob + h)             = (unsigned short)(q0[0] | (q0[2] << 8));
+        *reinterpret_cast<unsigned short *>(ob + 256 + h)       = (unsigned short)(q0[1] | (q0[3] << 8));
+        *reinterpret_cast<unsigned short *>(ob + 128 + h)       = (unsigned short)(q1[0] | (q1[2] << 8));
+        *reinterpret_cast<unsigned short *>(ob + 256 + 128 + h) = (unsigned short)(q1[1] | (q1[3] << 8));
+        wave_lds_sync();
+        uint2 *dst = reinterpret_cast<uint2 *>(mag + (size_t)frame * kMagArray + (size_t)row * 512);
+        dst[lane] = reinterpret_cast<const uint2 *>(ob)[lane];
+        wave_lds_sync();
+
+        ++step;
+        if (xcd_order) item = xcd_item(step, nframes);
+        else { item += (int)gridDim.x; if (item >= nitems) item = -1; }
+    }
+}
+
 }  // namespace
 
 hipError_t launch_waterfall(const float *iq, uint8_t *mag, const Ft8Tables *tab, int nframes,
@@ -306,6 +433,14 @@ hipError_t launch_waterfall(const float *iq, uint8_t *mag, const Ft8Tables *tab,
     if (grid < 1) return hipSuccess;
     // XCD-aware order needs whole groups of 8 workgroups and enough frames to give every XCD work
     const int xcd_order = (grid % 8 == 0 && nframes >= 64) ? 1 : 0;
+    static const int form = [] { const char *e = getenv("FT8GPU_WATERFALL_FORM"); return e ? atoi(e) : 1; }();
+    if (form == 2) {
+        int grid2 = num_cus * 16;                  // four resident workgroups per CU, four rounds of them
+        if (grid2 > nitems) grid2 = nitems;
+        const int xo = (grid2 % 8 == 0 && nframes >= 64) ? 1 : 0;
+        hipLaunchKernelGGL(ft8_waterfall_kernel_v2, dim3(grid2), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xo);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(ft8_waterfall_kernel, dim3(grid), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xcd_order);
     return hipGetLastError();
 }

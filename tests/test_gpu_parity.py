@@ -5,12 +5,15 @@ same inputs.  Bit-exact at every stage boundary:
   identical operation order, -ffp-contract=off on both sides), CRC, text, spot records.
 north_star's float tolerance for sync scores (1e-4) is moot: scores are integers and compared exactly.
 """
+import os
+
 import numpy as np
 import pytest
 
 import synth_util as S
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 MAG = 94208
 
@@ -743,3 +746,31 @@ def test_decode_randomised_waterfall_sweep(oracle, gpu_decoder):
             total += len(ref)
             conv += sum(r["ldpc_errors"] == 0 for r in ref)
     assert total == 3840
+
+
+def test_waterfall_second_form_is_bit_identical(oracle, tmp_path):
+    """ft8_waterfall_kernel_v2 (FT8GPU_WATERFALL_FORM=2: direct global loads, four workgroups per CU) must produce the
+    same bytes as the oracle; the form is chosen once per process, so a child process runs it"""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.path.join(os.environ["FT8_ROOT"], "tests")); sys.path.insert(0, os.environ["FT8_ROOT"])
+import oracle_lib, synth_util as S, rtlsdr_ft8d_amd as ft8
+oracle_lib.lib()
+enc = S.oracle_encode_fn(oracle_lib)
+frames = [np.stack(oracle_lib.selftest_signal())] + [S.make_frame(s, n, enc)[0] for s, n in ((3, 5), (4, 30), (5, 0))]
+frames.append(np.zeros((2, 48000), np.float32))
+rng = np.random.default_rng(2); big = rng.normal(0, 0.2, (300, 2, 48000)).astype(np.float32)     # enough frames for the XCD-aware order
+iq = np.concatenate([np.stack(frames), big])
+with ft8.Decoder(device=0, max_frames=iq.shape[0]) as d:
+    mag = d.waterfall(iq)
+    dec, n = d.decode_batch(iq[:5])
+bad = [k for k in list(range(5)) + [5, 100, 304] if not np.array_equal(mag[k], oracle_lib.waterfall(iq[k, 0], iq[k, 1]))]
+ref = [oracle_lib.subsystem(iq[k, 0], iq[k, 1]) for k in range(5)]
+ok = all(n[k] == ref[k][1] and dec[k].tobytes() == ref[k][0].tobytes() for k in range(5))
+print("RESULT", bad, ok)
+'''
+    env = dict(os.environ, FT8GPU_WATERFALL_FORM="2", FT8_ROOT=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert "RESULT [] True" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
