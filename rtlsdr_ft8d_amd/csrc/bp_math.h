@@ -118,17 +118,22 @@ __device__ __forceinline__ float tanh_one(float x) {
 }
 
 // ---- fast_atanh() of ft8_lib ldpc.c
+// (fast form: x2 * 64 is a scaling by a power of two, hence exact, so -735 + x2 * 64 is ONE rounding either way and a
+// fused multiply-add returns the very same float -- one instruction less per pair; the exhaustive self-test compares
+// it with the reference's two-operation form like everything else in this header)
 template <bool FAST>
 __device__ __forceinline__ f2 atanh_pair(f2 x) {
     const f2 x2 = x * x;
-    const f2 a = x * (945.0f + x2 * (-735.0f + x2 * 64.0f));
+    const f2 inner = FAST ? pk_fma(x2, f2{ 64.0f, 64.0f }, f2{ -735.0f, -735.0f }) : (-735.0f + x2 * 64.0f);
+    const f2 a = x * (945.0f + x2 * inner);
     const f2 b = (945.0f + x2 * (-1050.0f + x2 * 225.0f));
     return FAST ? div_pair_3(a, b) : div_pair_ieee(a, b);
 }
 template <bool FAST>
 __device__ __forceinline__ float atanh_one(float x) {
     const float x2 = x * x;
-    const float a = x * (945.0f + x2 * (-735.0f + x2 * 64.0f));
+    const float inner = FAST ? __builtin_fmaf(x2, 64.0f, -735.0f) : (-735.0f + x2 * 64.0f);
+    const float a = x * (945.0f + x2 * inner);
     const float b = (945.0f + x2 * (-1050.0f + x2 * 225.0f));
     return FAST ? div_one_3(a, b) : __fdiv_rn(a, b);
 }
