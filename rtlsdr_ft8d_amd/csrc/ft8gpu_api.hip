@@ -325,7 +325,8 @@ static int create_body(ft8gpu_ctx *c) {
     HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
     for (auto &e : c->dep) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIP_TRY(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+    // (the upload stream of the host-buffer path is created on first use: a context that only sees device pointers
+    // keeps its three streams on three hardware queues of their own)
     for (auto &e : c->copied) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     // process-wide defaults of the per-context test hooks (ft8gpu_set_debug_flags overrides them)
     { const char *e = getenv("FT8GPU_OVERLAP"); if (e && e[0] == '0') c->debug_flags |= FT8GPU_DBG_NO_OVERLAP; }
@@ -556,6 +557,7 @@ int ft8gpu_decode_batch(ft8gpu_ctx *c, const float *iq, int nframes, struct deco
             int k = 0;
             for (int g0 = 0; g0 < n; g0 += chunk, k++) {
                 const int m = (n - g0 < chunk) ? n - g0 : chunk;
+                if (chunk < n && !c->copy) HIP_TRY(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
                 hipStream_t up = (chunk < n) ? c->copy : c->stream;
                 HIP_TRY(hipMemcpyAsync(c->d_iq + g0 * frame_floats, iq + (f0 + g0) * frame_floats, m * frame_floats * sizeof(float),
                                        hipMemcpyHostToDevice, up));
