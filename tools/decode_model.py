@@ -33,11 +33,32 @@ sys.path.insert(0, ROOT)
 def slot_rate():
     """(wave64 v_mul_f32 per second per SIMD, raw line) from the micro-benchmark"""
     out = subprocess.run([os.path.join(ROOT, "tools", "ubench", "valu_rate")], capture_output=True, text=True, timeout=120).stdout
-    m = re.search(r"v_mul_f32\s*:\s*[\d.]+ ms\s+([\d.]+) Gop/s", out)
-    pk = re.search(r"v_pk_mul_f32\s*:\s*[\d.]+ ms\s+([\d.]+) Gop/s", out)
-    rcp = re.search(r"v_rcp_f32\s*:\s*[\d.]+ ms\s+([\d.]+) Gop/s", out)
-    g = float(m.group(1)) * 1e9 / 64 / 1024
-    return g, float(m.group(1)) / float(pk.group(1)), float(m.group(1)) / float(rcp.group(1))
+    rate = lambda name: float(re.search(name + r"\s*:\s*[\d.]+ ms\s+([\d.]+) Gop/s", out).group(1))
+    mul = rate("v_mul_f32")
+    g = mul * 1e9 / 64 / 1024
+    return g, {"pk": mul / rate("v_pk_mul_f32"), "rcp": mul / rate("v_rcp_f32"), "fma": mul / rate("v_fma_f32"), "vop3": mul / rate("v_bfi_b32")}
+
+
+FMA_OPS = ("v_fma_f32", "v_fmac_f32", "v_fmamk_f32", "v_fmaak_f32")
+VOP3_OPS = ("v_bfi_b32", "v_min3_", "v_max3_", "v_med3_", "v_perm_b32", "v_alignbit", "v_add3_u32", "v_lshl_add_u32", "v_and_or_b32", "v_lshl_or_b32")
+
+
+def price(opcodes, cost):
+    """VALU issue slots of an opcode histogram (one slot = one v_mul_f32)"""
+    total = 0.0
+    for op, k in opcodes.items():
+        if op.startswith("v_pk_"):
+            c = cost["pk"]
+        elif op.startswith("v_rcp_"):
+            c = cost["rcp"]
+        elif op.startswith(FMA_OPS):
+            c = cost["fma"]
+        elif op.startswith(VOP3_OPS):
+            c = cost["vop3"]
+        else:
+            c = 1.0
+        total += c * k
+    return total
 
 
 def main():
@@ -88,7 +109,7 @@ def main():
     for _ in range(5):
         dec.decode_batch_dev(iq, B, spots, nres)
     dec.synchronize()
-    rate, pk_cost, rcp_cost = slot_rate()
+    rate, cost = slot_rate()
     dec.enable_timing(True)
     with ClockSampler(0) as clk:
         clk_period = 0.005
@@ -99,11 +120,13 @@ def main():
         wall = time.perf_counter() - t0
     t = dec.timings()
     dec.enable_timing(False)
-    rate2, _, _ = slot_rate()
+    rate2, cost2 = slot_rate()
+    cost = {k: 0.5 * (cost[k] + cost2[k]) for k in cost}
+    pk_cost, rcp_cost = cost["pk"], cost["rcp"]
     t_slot = 2.0 / (rate + rate2)
 
     per_iter = cen["per_iteration_fast_path"]
-    s_iter = per_iter["valu"] + pk_cost * per_iter["valu_pk"] + rcp_cost * per_iter["trans"]
+    s_iter = price(cen["per_iteration_valu_opcodes"], cost)
     pro = cen["prologue_straight_line"]
     s_pro = pro.get("valu", 0) + pk_cost * pro.get("valu_pk", 0) + rcp_cost * pro.get("trans", 0)
     # epilogue: status record for everybody (about 60 VALU: the 48-byte record is assembled by lane 0); codewords add the
@@ -123,10 +146,10 @@ def main():
                   "mean_iterations_per_candidate": round(float(iters.mean()), 3),
                   "share_running_all_20": round(float((iters >= 20).mean()), 4), "iterations_histogram_0_20": hist.tolist()},
         "slot": {"v_mul_f32_wave_instr_per_s_per_simd": round((rate + rate2) / 2, 1), "ns": round(t_slot * 1e9, 4),
-                 "pk_cost_measured": round(pk_cost, 3), "rcp_cost_measured": round(rcp_cost, 3),
+                 "cost_in_slots_measured": {k: round(v, 3) for k, v in cost.items()},
                  "source": "tools/ubench/valu_rate run before and after the timed decode (mean)"},
         "census": {"file": os.path.relpath(args.census, ROOT), "slots_per_iteration": round(s_iter, 1), "slots_prologue": round(s_pro, 1),
-                   "slots_epilogue_assumed": s_epi, "per_iteration": per_iter},
+                   "slots_epilogue_assumed": s_epi, "per_iteration": per_iter, "per_iteration_valu_opcodes": cen["per_iteration_valu_opcodes"]},
         "model_ms_at_100pct_valu_issue": round(model_ms, 4),
         "measured_decode_ms": round(t["decode_ms"], 4), "measured_step_ms": round(1e3 * wall / 20, 4),
         "implied_valu_issue_utilisation": round(model_ms / t["decode_ms"], 4),

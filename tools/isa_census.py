@@ -138,7 +138,11 @@ def main():
             c[k] = c.get(k, 0) + 1
         ieee = any(op.startswith(("v_div_scale", "v_div_fmas", "v_div_fixup")) for op in ops)
         fast = (not ieee) and any(op == "v_rcp_f32_e32" or op.startswith("v_rcp_f32") for op in ops)
-        rows.append({"block": lab, "n": len(ops), "stream": "ieee" if ieee else ("fast" if fast else "shared"), **c,
+        hist = {}
+        for op in ops:
+            if op.startswith("v_"):
+                hist[op] = hist.get(op, 0) + 1
+        rows.append({"block": lab, "n": len(ops), "stream": "ieee" if ieee else ("fast" if fast else "shared"), **c, "valu_opcodes": hist,
                      "popcnt": sum(op.startswith(("v_bcnt", "s_bcnt1")) for op in ops),
                      "ballot_cmp": sum(op.startswith("v_cmp") for op in ops)})
     keys = ("valu", "valu_pk", "trans", "salu", "s_nop", "s_waitcnt", "lds", "vmem")
@@ -157,7 +161,8 @@ def main():
     # the scalar group screen passes, about one iteration in eight) and the exact guard key (integer minima; taken
     # when a row product is zero or below 2^-59: the first two iterations)
     for r, (lab, hdr, ops, text) in zip(rows, [b for b in blocks if b[1] == loop]):
-        r["rare"] = bool(r.get("vmem", 0) > 0 or sum(op.startswith("v_min_u32") for op in ops) >= 4)
+        only_moves = len(ops) > 0 and all(op.startswith("v_mov") for op in ops)          # zero-initialisation of the messages: iteration 0 only
+        r["rare"] = bool(r.get("vmem", 0) > 0 or sum(op.startswith("v_min_u32") for op in ops) >= 4 or only_moves)
     if args.v:
         print(f"{'block':12s} {'stream':8s} " + " ".join(f"{k:>9s}" for k in keys) + "  rare")
         for r in rows:
@@ -176,11 +181,17 @@ def main():
     rare = total(("fast", "fast*", "common"), rare=True)
     shared_all = common
     per_iter = {k: fast[k] + common[k] for k in keys}
+    opcodes = {}
+    for r in rows:
+        if r["stream"] in ("fast", "fast*", "common") and not r["rare"]:
+            for op, k in r["valu_opcodes"].items():
+                opcodes[op] = opcodes.get(op, 0) + k
     costs = {"valu": 1.0, "valu_pk": args.pk_cost, "trans": args.trans_cost}
     slots = sum(per_iter[k] * c for k, c in costs.items())
     out = {"kernel": args.kernel, "loop_header": loop, "blocks": rows,
            "fast_stream": fast, "ieee_stream": total(("ieee", "ieee*")), "common_blocks": common, "rarely_executed_on_the_fast_path": rare,
            "per_iteration_fast_path": per_iter,
+           "per_iteration_valu_opcodes": dict(sorted(opcodes.items(), key=lambda kv: -kv[1])),
            "prologue_straight_line": prologue,
            "epilogue_all_paths_static": epilogue_all,
            "prologue_valu_issue_slots": round(prologue.get("valu", 0) + args.pk_cost * prologue.get("valu_pk", 0) + args.trans_cost * prologue.get("trans", 0), 1),
