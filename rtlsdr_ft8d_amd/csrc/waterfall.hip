@@ -18,6 +18,7 @@
 //   * arithmetic order of the FFT is the "R4DIF-1024" order documented in DESIGN.md; compiled with
 //     -ffp-contract=off so every float operation is a single IEEE operation.
 #include "ft8gpu_internal.h"
+#include "quad_transpose.h"
 #include <stdlib.h>
 
 namespace {
@@ -153,6 +154,42 @@ __device__ __forceinline__ const float4 *item_vec(const float *__restrict__ iq, 
     return reinterpret_cast<const float4 *>(base + plane * kNSamples) + i;
 }
 
+
+// Last radix-4 stage + quantiser + row store, form without the second LDS exchange.  After stages 2 and 3 lane
+// (b, j) = (lane >> 2, lane & 3) holds point 64 b + j + 4 a in register a, and the inputs 4c .. 4c+3 of stage-4 butterfly
+// c = 16 b + a are register a of the four lanes of quad b: a 4 x 4 transpose inside the quad (quad_transpose.h: fused
+// select + quad permute, 64 single-rate VALU instructions per row) hands lane j all four inputs of the butterflies
+// c = 16 b + 4 i + j, i = 0..3 -- no 8 KB round trip through the LDS store path, which is what bounds this kernel.
+// Outputs are in digit-reversed order: butterfly c holds bins rev4(c) and 256 + rev4(c), rev4(c) = (b >> 2) + 4 (b & 3) +
+// 16 i + 64 j.  Same butterflies, same operation order: bit-identical to the exchange form.
+__device__ __forceinline__ void stage4_quad(c32 (&x)[16], int lane, const float *s_thr, unsigned char *ob) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float r0 = x[4 * i].x, r1 = x[4 * i + 1].x, r2 = x[4 * i + 2].x, r3 = x[4 * i + 3].x;
+        float m0 = x[4 * i].y, m1 = x[4 * i + 1].y, m2 = x[4 * i + 2].y, m3 = x[4 * i + 3].y;
+        quad_transpose4x2(r0, r1, r2, r3, m0, m1, m2, m3);
+        x[4 * i] = c32{ r0, m0 };
+        x[4 * i + 1] = c32{ r1, m1 };
+        x[4 * i + 2] = c32{ r2, m2 };
+        x[4 * i + 3] = c32{ r3, m3 };
+    }
+    const int b = lane >> 2, j = lane & 3;
+    const int kbase = (b >> 2) + 4 * (b & 3) + 64 * j;
+    unsigned char *o0 = ob + 256 * (kbase & 1) + (kbase >> 1);            // [freq_sub = k & 1][pos = k >> 1], bins kbase + 16 i
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const c32 a0 = x[4 * i], a1 = x[4 * i + 1], a2 = x[4 * i + 2], a3 = x[4 * i + 3];
+        const c32 t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = a1 - a3;
+        const c32 y0 = t0 + t2;
+        const c32 y1 = add_mul_mi(t1, t3);
+        unsigned q0, q1;
+        quantise2(y0, y1, s_thr, q0, q1);
+        o0[8 * i] = (unsigned char)q0;                                    // bin kbase + 16 i
+        o0[128 + 8 * i] = (unsigned char)q1;                              // bin 256 + kbase + 16 i
+    }
+}
+
+template <bool QUAD4>
 __global__ __launch_bounds__(256)
 void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ mag,
                           const Ft8Tables *__restrict__ tab, int nitems, int nframes, int xcd_order) {
@@ -261,32 +298,37 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
                 x[a] = c32{ v.x, v.y };
             }
             pass16(x, twA2, twB2);              // stages 2, 3
-#pragma unroll
-            for (int a = 0; a < 16; ++a) xb[wbase2[a & 3] + 8 * (a >> 2)] = make_float2(x[a].x, x[a].y);
-            wave_lds_sync();
-
-            // stage 4 (L = 4, no twiddles): butterfly c = lane + 64*i holds bins k0+i (y0) and 256+k0+i (y1)
-            unsigned q0[4], q1[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 *src = reinterpret_cast<const float4 *>(xb + rbase2 + 128 * i);      // butterfly c = lane + 64 i
-                const float4 v01 = src[0], v23 = src[kHalfUnits];
-                const c32 a0 = { v01.x, v01.y }, a1 = { v01.z, v01.w }, a2 = { v23.x, v23.y }, a3 = { v23.z, v23.w };
-                const c32 t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = a1 - a3;
-                const c32 y0 = t0 + t2;
-                const c32 y1 = add_mul_mi(t1, t3);
-                quantise2(y0, y1, s_thr, q0[i], q1[i]);
+            if (QUAD4) {
+                wave_lds_sync();                    // every lane has read its stage-2 inputs out of xb: its front becomes the row's output bytes
+                stage4_quad(x, lane, s_thr, ob);
+            } else {
+    #pragma unroll
+                for (int a = 0; a < 16; ++a) xb[wbase2[a & 3] + 8 * (a >> 2)] = make_float2(x[a].x, x[a].y);
+                wave_lds_sync();
+    
+                // stage 4 (L = 4, no twiddles): butterfly c = lane + 64*i holds bins k0+i (y0) and 256+k0+i (y1)
+                unsigned q0[4], q1[4];
+    #pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 *src = reinterpret_cast<const float4 *>(xb + rbase2 + 128 * i);      // butterfly c = lane + 64 i
+                    const float4 v01 = src[0], v23 = src[kHalfUnits];
+                    const c32 a0 = { v01.x, v01.y }, a1 = { v01.z, v01.w }, a2 = { v23.x, v23.y }, a3 = { v23.z, v23.w };
+                    const c32 t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = a1 - a3;
+                    const c32 y0 = t0 + t2;
+                    const c32 y1 = add_mul_mi(t1, t3);
+                    quantise2(y0, y1, s_thr, q0[i], q1[i]);
+                }
+                // ob aliases the front of xb (float4 loads above, 16-bit stores below, different types): make the order
+                // "every lane's stage-4 loads, then the stores" explicit instead of leaving it to the schedule
+                wave_lds_sync();
+                // bins k0..k0+3 -> [freq_sub = k&1][pos = k>>1]  (rtlsdr_ft8d.c:1420-1428)
+                const int k0 = 64 * (lane & 3) + 16 * ((lane >> 2) & 3) + 4 * (lane >> 4);
+                const int h = k0 >> 1;
+                *reinterpret_cast<unsigned short *>(ob + h)             = (unsigned short)(q0[0] | (q0[2] << 8));
+                *reinterpret_cast<unsigned short *>(ob + 256 + h)       = (unsigned short)(q0[1] | (q0[3] << 8));
+                *reinterpret_cast<unsigned short *>(ob + 128 + h)       = (unsigned short)(q1[0] | (q1[2] << 8));
+                *reinterpret_cast<unsigned short *>(ob + 256 + 128 + h) = (unsigned short)(q1[1] | (q1[3] << 8));
             }
-            // ob aliases the front of xb (float4 loads above, 16-bit stores below, different types): make the order
-            // "every lane's stage-4 loads, then the stores" explicit instead of leaving it to the schedule
-            wave_lds_sync();
-            // bins k0..k0+3 -> [freq_sub = k&1][pos = k>>1]  (rtlsdr_ft8d.c:1420-1428)
-            const int k0 = 64 * (lane & 3) + 16 * ((lane >> 2) & 3) + 4 * (lane >> 4);
-            const int h = k0 >> 1;
-            *reinterpret_cast<unsigned short *>(ob + h)             = (unsigned short)(q0[0] | (q0[2] << 8));
-            *reinterpret_cast<unsigned short *>(ob + 256 + h)       = (unsigned short)(q0[1] | (q0[3] << 8));
-            *reinterpret_cast<unsigned short *>(ob + 128 + h)       = (unsigned short)(q1[0] | (q1[2] << 8));
-            *reinterpret_cast<unsigned short *>(ob + 256 + 128 + h) = (unsigned short)(q1[1] | (q1[3] << 8));
             wave_lds_sync();
             const int row = chunk * kWfRowsPerItem + row_in_item;       // = 2*idx_block + time_sub
             uint2 *dst = reinterpret_cast<uint2 *>(mag + (size_t)frame * kMagArray + (size_t)row * 512);
@@ -319,6 +361,7 @@ __device__ __forceinline__ void bfly_stage_b(c32 (&x)[16], int q, float2 w1, flo
     x[4 * q + 3] = cmul(x[4 * q + 3], w3);
 }
 
+template <bool QUAD4>
 __global__ __launch_bounds__(256, 4)
 void ft8_waterfall_kernel_v2(const float *__restrict__ iq, uint8_t *__restrict__ mag,
                              const Ft8Tables *__restrict__ tab, int nitems, int nframes, int xcd_order) {
@@ -390,28 +433,33 @@ void ft8_waterfall_kernel_v2(const float *__restrict__ iq, uint8_t *__restrict__
 #pragma unroll
             for (int q = 0; q < 4; ++q) bfly_stage_b(x, q, w1, w2, w3);
         }
-#pragma unroll
-        for (int a = 0; a < 16; ++a) xb[wbase2[a & 3] + 8 * (a >> 2)] = make_float2(x[a].x, x[a].y);
-        wave_lds_sync();
-
-        unsigned q0[4], q1[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float4 *src = reinterpret_cast<const float4 *>(xb + rbase2 + 128 * i);
-            const float4 v01 = src[0], v23 = src[kHalfUnits];
-            const c32 a0 = { v01.x, v01.y }, a1 = { v01.z, v01.w }, a2 = { v23.x, v23.y }, a3 = { v23.z, v23.w };
-            const c32 t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = a1 - a3;
-            const c32 y0 = t0 + t2;
-            const c32 y1 = add_mul_mi(t1, t3);
-            quantise2(y0, y1, s_thr, q0[i], q1[i]);
+        if (QUAD4) {
+            wave_lds_sync();
+            stage4_quad(x, lane, s_thr, ob);
+        } else {
+    #pragma unroll
+            for (int a = 0; a < 16; ++a) xb[wbase2[a & 3] + 8 * (a >> 2)] = make_float2(x[a].x, x[a].y);
+            wave_lds_sync();
+    
+            unsigned q0[4], q1[4];
+    #pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 *src = reinterpret_cast<const float4 *>(xb + rbase2 + 128 * i);
+                const float4 v01 = src[0], v23 = src[kHalfUnits];
+                const c32 a0 = { v01.x, v01.y }, a1 = { v01.z, v01.w }, a2 = { v23.x, v23.y }, a3 = { v23.z, v23.w };
+                const c32 t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = a1 - a3;
+                const c32 y0 = t0 + t2;
+                const c32 y1 = add_mul_mi(t1, t3);
+                quantise2(y0, y1, s_thr, q0[i], q1[i]);
+            }
+            wave_lds_sync();                            // every lane's stage-4 loads before the stores into the same bytes
+            const int k0 = 64 * (lane & 3) + 16 * ((lane >> 2) & 3) + 4 * (lane >> 4);
+            const int h = k0 >> 1;
+            *reinterpret_cast<unsigned short *>(ob + h)             = (unsigned short)(q0[0] | (q0[2] << 8));
+            *reinterpret_cast<unsigned short *>(ob + 256 + h)       = (unsigned short)(q0[1] | (q0[3] << 8));
+            *reinterpret_cast<unsigned short *>(ob + 128 + h)       = (unsigned short)(q1[0] | (q1[2] << 8));
+            *reinterpret_cast<unsigned short *>(ob + 256 + 128 + h) = (unsigned short)(q1[1] | (q1[3] << 8));
         }
-        wave_lds_sync();                            // every lane's stage-4 loads before the stores into the same bytes
-        const int k0 = 64 * (lane & 3) + 16 * ((lane >> 2) & 3) + 4 * (lane >> 4);
-        const int h = k0 >> 1;
-        *reinterpret_cast<unsigned short *>(ob + h)             = (unsigned short)(q0[0] | (q0[2] << 8));
-        *reinterpret_cast<unsigned short *>(ob + 256 + h)       = (unsigned short)(q0[1] | (q0[3] << 8));
-        *reinterpret_cast<unsigned short *>(ob + 128 + h)       = (unsigned short)(q1[0] | (q1[2] << 8));
-        *reinterpret_cast<unsigned short *>(ob + 256 + 128 + h) = (unsigned short)(q1[1] | (q1[3] << 8));
         wave_lds_sync();
         uint2 *dst = reinterpret_cast<uint2 *>(mag + (size_t)frame * kMagArray + (size_t)row * 512);
         dst[lane] = reinterpret_cast<const uint2 *>(ob)[lane];
@@ -434,13 +482,17 @@ hipError_t launch_waterfall(const float *iq, uint8_t *mag, const Ft8Tables *tab,
     // XCD-aware order needs whole groups of 8 workgroups and enough frames to give every XCD work
     const int xcd_order = (grid % 8 == 0 && nframes >= 64) ? 1 : 0;
     static const int form = [] { const char *e = getenv("FT8GPU_WATERFALL_FORM"); return e ? atoi(e) : 1; }();
+    // last stage: second exchange through LDS (default) or "quad": 4 x 4 transposes inside the quads, no second exchange
+    static const bool quad4 = [] { const char *e = getenv("FT8GPU_WATERFALL_STAGE4"); return e && e[0] == 'q'; }();
     if (form == 2) {
         int grid2 = num_cus * 16;                  // four resident workgroups per CU, four rounds of them
         if (grid2 > nitems) grid2 = nitems;
         const int xo = (grid2 % 8 == 0 && nframes >= 64) ? 1 : 0;
-        hipLaunchKernelGGL(ft8_waterfall_kernel_v2, dim3(grid2), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xo);
+        if (quad4) hipLaunchKernelGGL(ft8_waterfall_kernel_v2<true>, dim3(grid2), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xo);
+        else hipLaunchKernelGGL(ft8_waterfall_kernel_v2<false>, dim3(grid2), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xo);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(ft8_waterfall_kernel, dim3(grid), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xcd_order);
+    if (quad4) hipLaunchKernelGGL(ft8_waterfall_kernel<true>, dim3(grid), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xcd_order);
+    else hipLaunchKernelGGL(ft8_waterfall_kernel<false>, dim3(grid), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xcd_order);
     return hipGetLastError();
 }

@@ -748,9 +748,11 @@ def test_decode_randomised_waterfall_sweep(oracle, gpu_decoder):
     assert total == 3840
 
 
-def test_waterfall_second_form_is_bit_identical(oracle, tmp_path):
-    """ft8_waterfall_kernel_v2 (FT8GPU_WATERFALL_FORM=2: direct global loads, four workgroups per CU) must produce the
-    same bytes as the oracle; the form is chosen once per process, so a child process runs it"""
+@pytest.mark.parametrize("form,stage4", [("2", "lds"), ("2", "quad"), ("1", "quad")])
+def test_waterfall_other_forms_are_bit_identical(oracle, tmp_path, form, stage4):
+    """ft8_waterfall_kernel_v2 (FT8GPU_WATERFALL_FORM=2: direct global loads, four workgroups per CU) and the last stage
+    without the second LDS exchange (FT8GPU_WATERFALL_STAGE4=quad: 4 x 4 transposes inside the quads with fused select +
+    quad permute) must produce the same bytes as the oracle; the form is chosen once per process, so a child process runs it"""
     import subprocess
     import sys
     code = r'''
@@ -771,6 +773,6 @@ ref = [oracle_lib.subsystem(iq[k, 0], iq[k, 1]) for k in range(5)]
 ok = all(n[k] == ref[k][1] and dec[k].tobytes() == ref[k][0].tobytes() for k in range(5))
 print("RESULT", bad, ok)
 '''
-    env = dict(os.environ, FT8GPU_WATERFALL_FORM="2", FT8_ROOT=ROOT)
+    env = dict(os.environ, FT8GPU_WATERFALL_FORM=form, FT8GPU_WATERFALL_STAGE4=stage4, FT8_ROOT=ROOT)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert "RESULT [] True" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

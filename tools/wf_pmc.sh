@@ -1,6 +1,6 @@
 export TMPDIR=/tmp
 CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-legs --no-clock-sampler"
-for f in 1 2; do
+for f in ${FORMS:-1 2}; do
   export FT8GPU_WATERFALL_FORM=$f
   rm -rf gpurun_out/wfpmc$f; mkdir -p gpurun_out/wfpmc$f
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d gpurun_out/wfpmc$f/sq -o sq -- $CMD > gpurun_out/wfpmc$f/sq.log 2>&1
