@@ -31,13 +31,18 @@ sys.path.insert(0, ROOT)
 
 
 def slot_rate():
-    """(wave64 v_mul_f32 per second per SIMD, raw line) from the micro-benchmark"""
-    out = subprocess.run([os.path.join(ROOT, "tools", "ubench", "valu_rate")], capture_output=True, text=True, timeout=120).stdout
+    """(wave64 v_mul_f32 per second per SIMD, relative costs, median shader clock while it ran) from the micro-benchmark"""
+    from bench import ClockSampler
+    with ClockSampler(0) as clk:
+        out = subprocess.run([os.path.join(ROOT, "tools", "ubench", "valu_rate")], capture_output=True, text=True, timeout=120).stdout
+    slot_rate.sclk.append(clk.summary().get("sclk_mhz_median"))
     rate = lambda name: float(re.search(name + r"\s*:\s*[\d.]+ ms\s+([\d.]+) Gop/s", out).group(1))
     mul = rate("v_mul_f32")
     g = mul * 1e9 / 64 / 1024
     return g, {"pk": mul / rate("v_pk_mul_f32"), "rcp": mul / rate("v_rcp_f32"), "fma": mul / rate("v_fma_f32"), "vop3": mul / rate("v_bfi_b32")}
 
+
+slot_rate.sclk = []
 
 FMA_OPS = ("v_fma_f32", "v_fmac_f32", "v_fmamk_f32", "v_fmaak_f32")
 VOP3_OPS = ("v_bfi_b32", "v_min3_", "v_max3_", "v_med3_", "v_perm_b32", "v_alignbit", "v_add3_u32", "v_lshl_add_u32", "v_and_or_b32", "v_lshl_or_b32")
@@ -114,7 +119,7 @@ def main():
     with ClockSampler(0) as clk:
         clk_period = 0.005
         t0 = time.perf_counter()
-        for _ in range(20):
+        for _ in range(100):
             dec.decode_batch_dev(iq, B, spots, nres)
         dec.synchronize()
         wall = time.perf_counter() - t0
@@ -140,6 +145,11 @@ def main():
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("decode", {})
     except (OSError, ValueError):
         pass
+    # the slot time was measured on a lighter kernel that clocks higher (the LDPC kernel is power-limited): scale it by
+    # the ratio of the shader clocks sampled during the two (sysfs), when both are available
+    f_dec = clk.summary().get("sclk_mhz_median")
+    f_ub = [f for f in slot_rate.sclk if f]
+    clock_ratio = (sum(f_ub) / len(f_ub)) / f_dec if (f_dec and f_ub) else None
     out = {
         "batch": {"frames": B, "candidates": ncand, "codewords": int(codeword.sum()),
                   "bp_iterations_entered": int(iters.sum()), "iterations_with_message_update": int(full_updates.sum()),
@@ -151,12 +161,16 @@ def main():
         "census": {"file": os.path.relpath(args.census, ROOT), "slots_per_iteration": round(s_iter, 1), "slots_prologue": round(s_pro, 1),
                    "slots_epilogue_assumed": s_epi, "per_iteration": per_iter, "per_iteration_valu_opcodes": cen["per_iteration_valu_opcodes"]},
         "model_ms_at_100pct_valu_issue": round(model_ms, 4),
-        "measured_decode_ms": round(t["decode_ms"], 4), "measured_step_ms": round(1e3 * wall / 20, 4),
+        "measured_decode_ms": round(t["decode_ms"], 4), "measured_step_ms": round(1e3 * wall / 100, 4),
         "implied_valu_issue_utilisation": round(model_ms / t["decode_ms"], 4),
         "pmc_valu_busy_frac": pmc.get("valu_busy_frac"),
         "model_with_pmc_busy_ms": round(model_ms / pmc["valu_busy_frac"], 4) if pmc.get("valu_busy_frac") else None,
         "model_error_vs_measured": round(model_ms / pmc["valu_busy_frac"] / t["decode_ms"] - 1.0, 4) if pmc.get("valu_busy_frac") else None,
+        "clock_ratio_slot_benchmark_over_ldpc_kernel": round(clock_ratio, 4) if clock_ratio else None,
+        "model_clock_corrected_ms": round(model_ms * clock_ratio / pmc["valu_busy_frac"], 4) if (clock_ratio and pmc.get("valu_busy_frac")) else None,
+        "model_clock_corrected_error_vs_measured": round(model_ms * clock_ratio / pmc["valu_busy_frac"] / t["decode_ms"] - 1.0, 4) if (clock_ratio and pmc.get("valu_busy_frac")) else None,
         "gpu_during_the_timed_loop": clk.summary(),
+        "sclk_mhz_during_the_slot_benchmark": slot_rate.sclk,
     }
     dec.close()
     print(json.dumps(out, indent=1))
