@@ -776,3 +776,27 @@ print("RESULT", bad, ok)
     env = dict(os.environ, FT8GPU_WATERFALL_FORM=form, FT8GPU_WATERFALL_STAGE4=stage4, FT8_ROOT=ROOT)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert "RESULT [] True" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_gpu_against_the_independent_numpy_restatement(gpu_decoder, frames, oracle_mags):
+    """closes the triangle: the HIP kernels against tests/ft8_spec_decode.py (numpy float32 written from SURVEY Appendix A,
+    not from the oracle) directly -- all 35 856 sync scores, the ordered candidate list, and per candidate the
+    parity-error count, the BP iterations entered and the 91 packed bits"""
+    import ft8_spec_decode as spec
+    bp = spec.BP()
+    checked = 0
+    for k in (0, 3):                                          # the reference's self-test frame and a 20-signal frame
+        mag = oracle_mags[k]
+        sc = spec.score_map(mag)
+        assert np.array_equal(gpu_decoder.score_map(mag[None])[0].reshape(sc.shape), sc.astype(np.int16))
+        cands, counts = gpu_decoder.find_sync(mag[None])
+        mine = spec.find_sync(mag, 120, 10, scores=sc)
+        assert int(counts[0]) == len(mine)
+        got = [[int(c["score"]), int(c["time_offset"]), int(c["freq_offset"]), int(c["time_sub"]), int(c["freq_sub"])] for c in cands[0, :counts[0]]]
+        assert got == [list(c) for c in mine]
+        st = gpu_decoder.decode_candidates(mag[None], cands, counts)[0]
+        for c in range(min(len(mine), 40)):
+            errors, entered, a91 = spec.decode_candidate(bp, mag, mine[c], 20)
+            assert (int(st[c]["ldpc_errors"]), int(st[c]["iters"]), bytes(st[c]["a91"])) == (errors, entered, a91), (k, c)
+            checked += 1
+    assert checked > 40
