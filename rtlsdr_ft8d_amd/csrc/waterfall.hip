@@ -374,9 +374,6 @@ void ft8_waterfall_kernel_v2(const float *__restrict__ iq, uint8_t *__restrict__
     for (int i = tid; i < 260; i += 256) s_thr[i] = tab->qthr[i];
     s_tw4[tid] = tab->tw[4 * tid];
 
-    float hw[16];
-#pragma unroll
-    for (int a = 0; a < 16; ++a) hw[a] = tab->hann[lane + 64 * a];
     float2 twA1[4][3];                                                       // stage 0: L = 1024, every index occurs
     const int j2 = lane & 3, b16 = lane >> 2;
 #pragma unroll
@@ -401,11 +398,15 @@ void ft8_waterfall_kernel_v2(const float *__restrict__ iq, uint8_t *__restrict__
         const float *pI = iq + (size_t)frame * (2 * kNSamples) + row * 256 + lane;
         const float *pQ = pI + kNSamples;
 
+        // window taps: re-read with every row (4 KB, L1-resident) instead of 16 VGPRs for the life of the wave -- with them
+        // four waves would fill the SIMD's register file and no other kernel's wave could run beside this one (the
+        // offset is always 0; it only keeps the loads inside the loop)
+        const float *hann = tab->hann + lane + (item >> 30);
         c32 x[16];
 #pragma unroll
         for (int a = 0; a < 16; ++a) x[a] = c32{ pI[64 * a], pQ[64 * a] };   // rtlsdr_ft8d.c:1407-1410
 #pragma unroll
-        for (int a = 0; a < 16; ++a) x[a] = x[a] * c32{ hw[a], hw[a] };
+        for (int a = 0; a < 16; ++a) { const float w = hann[64 * a]; x[a] = x[a] * c32{ w, w }; }
         // stages 0, 1
 #pragma unroll
         for (int a = 0; a < 4; ++a) bfly_stage_a(x, a, twA1[a][0], twA1[a][1], twA1[a][2]);
@@ -481,7 +482,8 @@ hipError_t launch_waterfall(const float *iq, uint8_t *mag, const Ft8Tables *tab,
     if (grid < 1) return hipSuccess;
     // XCD-aware order needs whole groups of 8 workgroups and enough frames to give every XCD work
     const int xcd_order = (grid % 8 == 0 && nframes >= 64) ? 1 : 0;
-    static const int form = [] { const char *e = getenv("FT8GPU_WATERFALL_FORM"); return e ? atoi(e) : 1; }();
+    // form 2 (four workgroups per CU, no staging buffer) is the product; FT8GPU_WATERFALL_FORM=1 selects the staged form
+    static const int form = [] { const char *e = getenv("FT8GPU_WATERFALL_FORM"); return e ? atoi(e) : 2; }();
     // last stage: second exchange through LDS (default) or "quad": 4 x 4 transposes inside the quads, no second exchange
     static const bool quad4 = [] { const char *e = getenv("FT8GPU_WATERFALL_STAGE4"); return e && e[0] == 'q'; }();
     if (form == 2) {

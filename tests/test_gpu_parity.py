@@ -748,10 +748,10 @@ def test_decode_randomised_waterfall_sweep(oracle, gpu_decoder):
     assert total == 3840
 
 
-@pytest.mark.parametrize("form,stage4", [("2", "lds"), ("2", "quad"), ("1", "quad")])
+@pytest.mark.parametrize("form,stage4", [("1", "lds"), ("2", "quad"), ("1", "quad")])
 def test_waterfall_other_forms_are_bit_identical(oracle, tmp_path, form, stage4):
-    """ft8_waterfall_kernel_v2 (FT8GPU_WATERFALL_FORM=2: direct global loads, four workgroups per CU) and the last stage
-    without the second LDS exchange (FT8GPU_WATERFALL_STAGE4=quad: 4 x 4 transposes inside the quads with fused select +
+    """the staged form of the waterfall kernel (FT8GPU_WATERFALL_FORM=1: 4-row items in LDS, three workgroups per CU; the
+    product is form 2: direct global loads, four workgroups per CU) and the last stage without the second LDS exchange (FT8GPU_WATERFALL_STAGE4=quad: 4 x 4 transposes inside the quads with fused select +
     quad permute) must produce the same bytes as the oracle; the form is chosen once per process, so a child process runs it"""
     import subprocess
     import sys
