@@ -210,12 +210,13 @@ int run_pipeline_overlapped(ft8gpu_ctx *c, const float *d_iq, int n, struct deco
     StageTimer t(c);
     const ft8gpu_params &p = c->params;
     const int mc = p.max_candidates;
-    // size of part A in 1/16ths of the batch, whole blocks of 64 frames.  Swept at 4096 frames in one session
-    // (profiles/r02_ab_kernels.json): 1/16 4.99 ms, 2/16 5.03, 4/16 5.03, 8/16 5.22; a later sweep in frames
-    // (128 ... 768) stayed within 4.978-4.992 ms: the size is not critical as long as it is small.
-    int sixteenths = n >= 2048 ? 1 : 2;
-    if (mc > 240) sixteenths *= 2;
-    int n0 = ((n * sixteenths / 16) + 63) & ~63;
+    // size of part A: a quarter of the batch in whole blocks of 64 frames.  Round 2 used 1/16 (its sweep, with the heap
+    // replay of part B on the same side stream as that of part A: 1/16 4.99 ms, 2/16 5.03, 4/16 5.03, 8/16 5.22).  With
+    // heap(B) on its own stream and the round-3 kernels the order is reversed -- 256 frames 4.23-4.26 ms, 512 4.25,
+    // 768 4.25, 1024 4.20-4.24, 1536 4.21-4.23, 2048 4.21 -- decode(A) then covers the whole replay of part B
+    // (whose dependent chain grows with the candidate cap, not with the number of frames) and the first LDPC launch fills
+    // the machine for longer.
+    int n0 = ((n / 4) + 63) & ~63;
     if (n0 < 64) n0 = 64;
     if (n0 > n - 64) n0 = n / 2;
     const int n1 = n - n0;
