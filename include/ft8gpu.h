@@ -99,10 +99,9 @@ typedef struct {
     float decode_ms;      /* LLR + LDPC BP + CRC + unpack */
     float spots_ms;       /* dedup + CQ spot fill */
     float total_ms;       /* first kernel start to last kernel end */
-    int32_t launches_per_stage; /* 1, or 2 when a large batch is processed as two overlapped parts (a small first
-                                   part and the rest): heap and spots of one part then run on a side stream under
-                                   the other part's kernels, and the per-stage figures are sums over both launches
-                                   (the waterfall stays one launch) */
+    int32_t launches_per_stage; /* 1, or 2 when a large batch is processed as two overlapped parts (the first quarter and the
+                                   rest): heap and spots of one part then run on side streams under the other part's kernels,
+                                   and the per-stage figures are sums over both launches of every stage */
 } ft8gpu_timings;
 
 /* ---- lifecycle: replaces initFFTW()/freeFFTW(), rtlsdr_ft8d.c:314-347 ----------------------- */

@@ -194,7 +194,7 @@ float elapsed(hipEvent_t a, hipEvent_t b) {
 }
 
 // Large batches: the two serial kernels (exact heap replay, spot collection) keep only one lane per frame
-// busy, so the batch is cut into a SMALL first part A and the rest B, and their serial kernels run on side
+// busy, so the batch is cut into a first part A (a quarter) and the rest B, and their serial kernels run on side
 // streams under the throughput kernels of the other part:
 //   main : wf(A) sync(A) wf(B) sync(B) ..wait heap(A).. decode(A) ..wait heap(B).. decode(B) spots(B)
 //   side :            heap(A)                                          spots(A)
