@@ -347,11 +347,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    dec.enable_timing(True)          # stage events are recorded on the stream, read after the fence
+    # the clock / power sampler starts before the warm-up so that its thread start-up does not land in the first timed step
     with ClockSampler(local_rank, not args.no_clock_sampler) as clk:
+        for _ in range(args.warmup):
+            step()
+        fence()
+        dec.enable_timing(True)          # stage events are recorded on the stream, read after the fence
+        clk.sclk.clear()
+        clk.power.clear()
         t0 = time.perf_counter()
         step_ev[0].record(stream)
         for i in range(args.steps):
@@ -373,6 +376,7 @@ def main():
     out["value"] = round(total * args.steps / elapsed, 1)
     out["ms_per_step"] = round(1e3 * elapsed / args.steps, 3)
     out["step_ms"] = {"min": round(min(per_step), 4), "median": round(float(np.median(per_step)), 4), "max": round(max(per_step), 4),
+                      "slowest_step_index": int(np.argmax(per_step)),
                       "note": "hipEvent time between consecutive steps' last kernels on rank 0's stream"}
     out["gpu_clock"] = clk.summary()
     out["config"]["decoded_messages_per_frame"] = round(float(nres.cpu().numpy().mean()), 2)
