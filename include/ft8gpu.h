@@ -13,6 +13,8 @@
  * Environment: FT8GPU_DEVICE=<n> GPU used by the drop-in ft8_subsystem (default 0).  The test hooks are
  * per-context flags (ft8gpu_set_debug_flags); FT8GPU_OVERLAP=0, FT8GPU_FORCE_IEEE_DIV=1 and
  * FT8GPU_DECODE_PIPELINE_FORM=1 only set their initial value for contexts created afterwards.
+ * FT8GPU_WATERFALL_FORM=1 / FT8GPU_WATERFALL_STAGE4=quad select the other (bit-identical) forms of the waterfall kernel,
+ * read once per process.
  */
 #ifndef FT8GPU_H
 #define FT8GPU_H
