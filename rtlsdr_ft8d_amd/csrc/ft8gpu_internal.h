@@ -18,9 +18,11 @@ constexpr int kMaxMessages = 50;     // K_MAX_MESSAGES
 constexpr int kT0Min = -12, kT0Count = 36, kF0Count = 249;
 constexpr int kSegments = 4;                                   // (time_sub, freq_sub)
 constexpr int kSyncWaves = 8;                                  // waves per sync workgroup
-constexpr int kT0PerWaveMax = (kT0Count + kSyncWaves - 1) / kSyncWaves;   // 5 (waves get 4 or 5 time offsets)
-constexpr int kSublistCap = kT0PerWaveMax * kF0Count;          // 1245 entries, worst case
-constexpr int kSublistsPerFrame = kSegments * kSyncWaves;      // 32
+constexpr int kSyncHalves = 2;                                 // a workgroup scores half of the time offsets of a segment
+constexpr int kT0PerHalf = kT0Count / kSyncHalves;             // 18
+constexpr int kT0PerWaveMax = (kT0PerHalf + kSyncWaves - 1) / kSyncWaves;   // 3 (waves get 2 or 3 time offsets)
+constexpr int kSublistCap = kT0PerWaveMax * kF0Count;          // 747 entries, worst case
+constexpr int kSublistsPerFrame = kSegments * kSyncHalves * kSyncWaves;     // 64, in scan order: segment, half, wave
 constexpr int kScoresPerFrame = kSegments * kT0Count * kF0Count; // 35856
 
 constexpr int kLdpcN = 174, kLdpcK = 91, kLdpcM = 83;

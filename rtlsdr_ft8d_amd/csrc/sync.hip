@@ -2,7 +2,7 @@
 // call site rtlsdr_ft8d.c:1450 (waterfall descriptor rtlsdr_ft8d.c:1440-1448).
 //
 // Two kernels:
-//   ft8_sync_kernel  one workgroup per (frame, time_sub, freq_sub).  ft8_sync_score() sums, over three
+//   ft8_sync_kernel  two workgroups per (frame, time_sub, freq_sub), each scoring half of the time offsets.  ft8_sync_score() sums, over three
 //                    Costas blocks m and seven symbols k, neighbour contrasts of the waterfall at block
 //                    b = t0 + 36 m + k.  Which terms exist depends on b and k only, never on the
 //                    frequency, so the sum over m is taken ONCE per (t0 + k) while the slice streams
@@ -30,11 +30,15 @@ namespace {
 // where each map is the sum of its symbol's contribution over the (up to three) m with b in range:
 //   MA[t'] for t' in [-11, 29)   M0[t'] for t' in [-12, 24)   M3[t'] for t' in [-9, 27)   M6[t'] for t' in [-6, 30)
 // Magnitudes: |cell| <= 3 * 4 * 255 = 3060, so int16 holds a cell and packed 16-bit arithmetic is exact.
+// A workgroup scores the time offsets t0 in [h0, h0 + 18) of one (time_sub, freq_sub) slice, h0 = -12 or 6 (two
+// workgroups per slice): it needs MA[t'] for t' in [h0 + 1, h0 + 23), M0 for [h0, h0 + 18), M3 for [h0 + 3, h0 + 21),
+// M6 for [h0 + 6, h0 + 24) -- 76 rows = 38.9 KB instead of the 148 rows (75.8 KB) of the whole range, i.e. four
+// resident workgroups (32 waves) per CU instead of two, for 14 % more map rows built in total.
 constexpr int kMapPitch = 256;                            // int16 per map row
-constexpr int kRowsA = 40, kRowsK = 36;                   // rows of MA / of M0, M3, M6
+constexpr int kRowsA = kT0PerHalf + 4, kRowsK = kT0PerHalf;   // rows of MA (22) / of M0, M3, M6 (18)
 constexpr int kOffA = 0, kOff0 = kRowsA, kOff3 = kRowsA + kRowsK, kOff6 = kRowsA + 2 * kRowsK;
-constexpr int kMapRows = kRowsA + 3 * kRowsK;             // 148 rows
-constexpr int kTqCount = 42;                              // t' = tq - 12 for tq in [0, 42)
+constexpr int kMapRows = kRowsA + 3 * kRowsK;             // 76 rows
+constexpr int kTqCount = kT0PerHalf + 6;                  // t' = h0 + tq for tq in [0, 24): 3 per wave
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
@@ -90,7 +94,8 @@ void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lis
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int frame = blockIdx.x >> 2, seg = blockIdx.x & 3;
+    const int frame = blockIdx.x >> 3, seg = (blockIdx.x >> 1) & 3, half = blockIdx.x & 1;
+    const int h0i = half * kT0PerHalf, h0 = h0i + kT0Min;        // first time offset of this workgroup: index and value
     const int ts = seg >> 1, fs = seg & 1;
     if (tid < kT0Count) s_navg[tid] = sync_navg(tid + kT0Min);   // (a loop of scalar branches when evaluated per row)
 
@@ -98,15 +103,15 @@ void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lis
     {
         const u32 *rows = reinterpret_cast<const u32 *>(mag + (size_t)frame * kMagArray + ts * 512 + fs * 256) + lane;
         const int tq_begin = (wave * kTqCount) / kSyncWaves, tq_end = ((wave + 1) * kTqCount) / kSyncWaves;
-        const int ntq = tq_end - tq_begin;                       // 5 or 6
-        constexpr int kMaxTq = (kTqCount + kSyncWaves - 1) / kSyncWaves;   // 6
-        // row j of Costas block m is block b = tq_begin - 12 + 36 m - 1 + j, j in [0, ntq + 2)
+        const int ntq = tq_end - tq_begin;                       // 3
+        constexpr int kMaxTq = (kTqCount + kSyncWaves - 1) / kSyncWaves;   // 3
+        // row j of Costas block m is block b = h0 + tq_begin + 36 m - 1 + j, j in [0, ntq + 2)
         u32 raw[3][kMaxTq + 2];
 #pragma unroll
         for (int m = 0; m < 3; ++m)
 #pragma unroll
             for (int j = 0; j < kMaxTq + 2; ++j) {
-                const int b = tq_begin - 12 + 36 * m - 1 + j;   // wave-uniform
+                const int b = h0 + tq_begin + 36 * m - 1 + j;   // wave-uniform
                 raw[m][j] = (j < ntq + 2 && b >= 0 && b < kNumBlocks) ? rows[(size_t)b * (kBlockStride / 4)] : 0u;
             }
         // (c0, c1) and (c2, c3) of a row as int16 pairs
@@ -117,7 +122,7 @@ void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lis
 #pragma unroll
         for (int i = 0; i < kMaxTq; ++i) {
             if (i < ntq) {                                       // wave-uniform
-                const int tp = tq_begin + i - 12;                // t'
+                const int tq = tq_begin + i, tp = h0 + tq;       // t'
                 const s16x2 zero = { 0, 0 };
                 s16x2 C[2] = { zero, zero }, Up[2] = { zero, zero }, Dn[2] = { zero, zero };
 #pragma unroll
@@ -154,10 +159,10 @@ void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lis
                     v.y = as_u32(b2);
                     *reinterpret_cast<uint2 *>(s_map + row * kMapPitch + 4 * lane) = v;
                 };
-                if (tp >= -11 && tp < 29) store(kOffA + tp + 11, S[0], S[1]);
-                if (tp >= -12 && tp < 24) store(kOff0 + tp + 12, S[0] - U[0], S[1] - U[1]);
-                if (tp >= -9 && tp < 27)  store(kOff3 + tp + 9, S[0] - W[0], S[1] - W[1]);
-                if (tp >= -6 && tp < 30)  store(kOff6 + tp + 6, S[0] - V[0], S[1] - V[1]);
+                if (tq >= 1 && tq < kRowsA + 1) store(kOffA + tq - 1, S[0], S[1]);                        // MA[t'], t' in [h0 + 1, h0 + 23)
+                if (tq < kRowsK)                store(kOff0 + tq, S[0] - U[0], S[1] - U[1]);              // M0[t'], [h0, h0 + 18)
+                if (tq >= 3 && tq < kRowsK + 3) store(kOff3 + tq - 3, S[0] - W[0], S[1] - W[1]);          // M3[t'], [h0 + 3, h0 + 21)
+                if (tq >= 6)                    store(kOff6 + tq - 6, S[0] - V[0], S[1] - V[1]);          // M6[t'], [h0 + 6, h0 + 24)
 #pragma unroll
                 for (int m = 0; m < 3; ++m)
 #pragma unroll
@@ -169,28 +174,29 @@ void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lis
     __syncthreads();
 
     // ---- score all positions: lane = frequency offsets 4 lane .. 4 lane + 3 ----------------------------
-    const int sub = seg * kSyncWaves + wave;
+    const int sub = (seg * kSyncHalves + half) * kSyncWaves + wave;      // scan order: segment, then time offset
     uint32_t *my_list = lists + ((size_t)frame * kSublistsPerFrame + sub) * kSublistCap;
     int count = 0;
-    const int t_begin = (wave * kT0Count) / kSyncWaves, t_end = ((wave + 1) * kT0Count) / kSyncWaves;
+    const int t_begin = (wave * kT0PerHalf) / kSyncWaves, t_end = ((wave + 1) * kT0PerHalf) / kSyncWaves;   // 2 or 3 local offsets
     // sign-bit masks of the cells that are real positions (f0 < 249): all four up to lane 61, one in lane 62
     const u32 vm_lo = lane < 62 ? 0x80008000u : (lane == 62 ? 0x00008000u : 0u);
     const u32 vm_hi = lane < 62 ? 0x80008000u : 0u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    for (int t0i = t_begin; t0i < t_end; ++t0i) {                // scan order: time_offset ascending
+    for (int tl = t_begin; tl < t_end; ++tl) {                   // scan order: time_offset ascending
+        const int t0i = h0i + tl;                                // index into the 36 time offsets
         const int navg = __builtin_amdgcn_readfirstlane(s_navg[t0i]);
         // trunc(num / navg) >= min_score  <=>  num >= T   (C division truncates toward zero; navg = 0 leaves the sum undivided)
         int T = navg > 0 ? (min_score > 0 ? min_score * navg : (min_score - 1) * navg + 1) : min_score;
         T = T > 32767 ? 32767 : (T < -32768 ? -32768 : T);       // |num| <= 21420: saturated thresholds mean never / always
         const s16x2 Tpk = { (short)T, (short)T };
-        const u32 *pa0 = reinterpret_cast<const u32 *>(s_map + (kOffA + t0i + 0) * kMapPitch) + 2 * lane;   // t' = t0 + 1
-        const u32 *pa1 = reinterpret_cast<const u32 *>(s_map + (kOffA + t0i + 1) * kMapPitch) + 2 * lane;   // t0 + 2
-        const u32 *pa3 = reinterpret_cast<const u32 *>(s_map + (kOffA + t0i + 3) * kMapPitch) + 2 * lane;   // t0 + 4
-        const u32 *pa4 = reinterpret_cast<const u32 *>(s_map + (kOffA + t0i + 4) * kMapPitch) + 2 * lane;   // t0 + 5
-        const u32 *p0 = reinterpret_cast<const u32 *>(s_map + (kOff0 + t0i) * kMapPitch) + 2 * lane;
-        const u32 *p3 = reinterpret_cast<const u32 *>(s_map + (kOff3 + t0i) * kMapPitch) + 2 * lane;
-        const u32 *p6 = reinterpret_cast<const u32 *>(s_map + (kOff6 + t0i) * kMapPitch) + 2 * lane;
+        const u32 *pa0 = reinterpret_cast<const u32 *>(s_map + (kOffA + tl + 0) * kMapPitch) + 2 * lane;   // t' = t0 + 1
+        const u32 *pa1 = reinterpret_cast<const u32 *>(s_map + (kOffA + tl + 1) * kMapPitch) + 2 * lane;   // t0 + 2
+        const u32 *pa3 = reinterpret_cast<const u32 *>(s_map + (kOffA + tl + 3) * kMapPitch) + 2 * lane;   // t0 + 4
+        const u32 *pa4 = reinterpret_cast<const u32 *>(s_map + (kOffA + tl + 4) * kMapPitch) + 2 * lane;   // t0 + 5
+        const u32 *p0 = reinterpret_cast<const u32 *>(s_map + (kOff0 + tl) * kMapPitch) + 2 * lane;
+        const u32 *p3 = reinterpret_cast<const u32 *>(s_map + (kOff3 + tl) * kMapPitch) + 2 * lane;
+        const u32 *p6 = reinterpret_cast<const u32 *>(s_map + (kOff6 + tl) * kMapPitch) + 2 * lane;
         // cells f0 + off .. f0 + off + 3 of a row as two packed pairs; dword d of the lane's pointer holds cells 2d, 2d + 1
         const u32 a0 = pa0[0], a1 = pa0[1], a2 = pa0[2];         // MA[t0+1], offset 1
         const u32 b2 = pa1[2], b3 = pa1[3];                      // MA[t0+2], offset 4
@@ -382,7 +388,7 @@ __device__ __forceinline__ void heap_select_regs(const uint32_t *__restrict__ fr
         advance(nsub, nbase);
         const uint32_t v_next = fetch(nsub, nbase);              // in flight while this chunk is replayed
         const int n = count_of(sub);
-        const uint32_t seg = (uint32_t)(sub / kSyncWaves);
+        const uint32_t seg = (uint32_t)(sub / (kSyncHalves * kSyncWaves));
         uint64_t c = 0;
         bool live = base + lane < n;
         if (live) {
@@ -451,7 +457,7 @@ void ft8_heap_kernel(const uint32_t *__restrict__ lists, const int32_t *__restri
     for (int sub = 0; sub < kSublistsPerFrame; ++sub) {          // (time_sub, freq_sub, time_offset) order
         const int n = list_counts[(size_t)frame * kSublistsPerFrame + sub];
         const uint32_t *l = lists + ((size_t)frame * kSublistsPerFrame + sub) * kSublistCap;
-        const uint32_t seg = (uint32_t)(sub / kSyncWaves);
+        const uint32_t seg = (uint32_t)(sub / (kSyncHalves * kSyncWaves));
         for (int base = 0; base < n; base += 64) {
             const int e = base + lane;
             uint64_t c = 0;
@@ -517,10 +523,10 @@ hipError_t launch_sync(const uint8_t *mag, uint32_t *lists, int32_t *list_counts
                        int nframes, int min_score, hipStream_t s) {
     if (nframes < 1) return hipSuccess;
     if (score_map)
-        hipLaunchKernelGGL(ft8_sync_kernel<true>, dim3(nframes * kSegments), dim3(64 * kSyncWaves), 0, s,
+        hipLaunchKernelGGL(ft8_sync_kernel<true>, dim3(nframes * kSegments * kSyncHalves), dim3(64 * kSyncWaves), 0, s,
                            mag, lists, list_counts, score_map, min_score);
     else
-        hipLaunchKernelGGL(ft8_sync_kernel<false>, dim3(nframes * kSegments), dim3(64 * kSyncWaves), 0, s,
+        hipLaunchKernelGGL(ft8_sync_kernel<false>, dim3(nframes * kSegments * kSyncHalves), dim3(64 * kSyncWaves), 0, s,
                            mag, lists, list_counts, score_map, min_score);
     return hipGetLastError();
 }
