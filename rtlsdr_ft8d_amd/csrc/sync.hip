@@ -94,7 +94,14 @@ void ft8_sync_kernel(const uint8_t *__restrict__ mag, uint32_t *__restrict__ lis
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int frame = blockIdx.x >> 3, seg = (blockIdx.x >> 1) & 3, half = blockIdx.x & 1;
+    // The two workgroups of a slice read the same waterfall rows (the second one 60 % of them); the dispatcher places
+    // block x on XCD x % 8 and every XCD has its own L2, so the halves of slice u sit 8 blocks apart -- same XCD, second
+    // read from L2 -- whenever the grid is a whole number of such groups of 16.  (Placement only affects cache traffic.)
+    const unsigned x = blockIdx.x;
+    const bool paired = (gridDim.x & 15u) == 0u;
+    const unsigned unit = paired ? (((x >> 4) << 3) | (x & 7u)) : (x >> 1);
+    const int half = paired ? (int)((x >> 3) & 1u) : (int)(x & 1u);
+    const int frame = (int)(unit >> 2), seg = (int)(unit & 3u);
     const int h0i = half * kT0PerHalf, h0 = h0i + kT0Min;        // first time offset of this workgroup: index and value
     const int ts = seg >> 1, fs = seg & 1;
     if (tid < kT0Count) s_navg[tid] = sync_navg(tid + kT0Min);   // (a loop of scalar branches when evaluated per row)
