@@ -288,6 +288,14 @@ def main():
         raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({ndev} visible); --gpus must not exceed the GPUs of the node")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # The decoder context -- and with it its three streams -- is created BEFORE the process group and before any torch
+    # stream: HIP hands streams to a few hardware queues in creation order, and the pipeline needs its main and its two side
+    # streams on three different queues.  (Created after RCCL's and torch's streams, the main and one side stream landed
+    # on the same queue and the heap replay of part A no longer ran beside the waterfall of part B: +0.27 ms per step,
+    # tools/trace_gaps.py on a rocprofv3 kernel trace.)
+    dec = None
+    if not (args.config == 3 and world == 1):
+        dec = ft8.Decoder(device=local_rank, max_frames=B, min_score=10, max_candidates=maxc, ldpc_iters=20)
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -301,7 +309,6 @@ def main():
         print(json.dumps(out), flush=True)
         return
 
-    dec = ft8.Decoder(device=local_rank, max_frames=B, min_score=10, max_candidates=maxc, ldpc_iters=20)
     # The decoder keeps its OWN stream (its main / side streams are created together and sit on distinct hardware
     # queues; on a borrowed torch stream the same pipeline measured 1.48 instead of 1.28 ms at 1024 frames, cap 480).
     # torch sees that stream as an ExternalStream (events, waits); the RCCL gather is issued from a torch stream that
