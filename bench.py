@@ -87,6 +87,10 @@ def parse_args(argv=None):
     ap.add_argument("--dry", action="store_true",
                     help="no GPU work: every rank fills its shard's spot buffers with a pattern derived from the global frame index and "
                          "runs the real exchange; checks launcher, sharding and gather (CPU tensors, gloo)")
+    ap.add_argument("--prewarm", type=int, default=8,
+                    help="untimed steps run before the W warm-up steps: after any idle period the GPU needs about 30 ms of load to "
+                         "reach its sustained clock (per-step times from cold: 5.65, 4.82, 4.67, 4.54, 4.48, 4.38, 4.25, 4.25 ... ms, "
+                         "tools/perstep_probe.py), which short --warmup values would put inside the timed region; reported in the line")
     ap.add_argument("--no-clock-sampler", action="store_true", help="do not poll the GPU's sysfs clock / power files during the timed region")
     ap.add_argument("--shards", type=int, default=8, help="configs[3] on one GPU: number of contexts / shards")
     return ap.parse_args(argv)
@@ -356,7 +360,7 @@ def main():
 
     # the clock / power sampler starts before the warm-up so that its thread start-up does not land in the first timed step
     with ClockSampler(local_rank, not args.no_clock_sampler) as clk:
-        for _ in range(args.warmup):
+        for _ in range(args.prewarm + args.warmup):
             step()
         fence()
         dec.enable_timing(True)          # stage events are recorded on the stream, read after the fence
@@ -386,6 +390,7 @@ def main():
                       "slowest_step_index": int(np.argmax(per_step)),
                       "note": "hipEvent time between consecutive steps' last kernels on rank 0's stream"}
     out["gpu_clock"] = clk.summary()
+    out["prewarm_steps"] = args.prewarm        # untimed, before the W warm-up steps (clock ramp after idle; see --prewarm)
     out["config"]["decoded_messages_per_frame"] = round(float(nres.cpu().numpy().mean()), 2)
     if use_dist and world > 1:
         # the gathered list of the last step must hold every rank's records in global frame order
