@@ -246,12 +246,18 @@ int run_pipeline_overlapped(ft8gpu_ctx *c, const float *d_iq, int n, struct deco
     // side streams: heap(A), heap(B)
     HIP_TRY(hipStreamWaitEvent(c->side, E[0], 0));
     t.mark_side(0);
-    HIP_TRY(launch_heap(c->d_lists, c->d_list_counts, c->d_cands, c->d_counts, n0, mc, c->side));
+    // The replay of part B runs beside the VALU-bound LDPC kernel of part A: from about 3000 frames on that kernel runs
+    // longer than the 0.55 ms of the one-lane-per-frame replay, which costs a tenth of the issue slots beside it.  The
+    // replay of part A runs beside the LDS-bound waterfall kernel, which has VALU slots to spare and no LDS bandwidth:
+    // there the wave-per-frame form (VALU lane moves, short chain) is the better neighbour.  Measured in one session:
+    // both wave-per-frame 4.157 ms, both lane-per-frame 4.116, this split 4.096.
+    const bool hide = n >= 3072;
+    HIP_TRY(launch_heap(c->d_lists, c->d_list_counts, c->d_cands, c->d_counts, n0, mc, c->side, false));
     t.mark_side(1);
     HIP_TRY(hipEventRecord(E[2], c->side));
     HIP_TRY(hipStreamWaitEvent(c->side2, E[1], 0));
     t.mark_on(c->side2, 2);
-    HIP_TRY(launch_heap(lists1, lc1, cands1, counts1, n1, mc, c->side2));
+    HIP_TRY(launch_heap(lists1, lc1, cands1, counts1, n1, mc, c->side2, hide));
     t.mark_on(c->side2, 3);
     HIP_TRY(hipEventRecord(E[3], c->side2));
     // main stream: decode(A), decode(B), spots(B)

@@ -21,7 +21,7 @@ constexpr int kSyncWaves = 8;                                  // waves per sync
 constexpr int kSyncHalves = 2;                                 // a workgroup scores half of the time offsets of a segment
 constexpr int kT0PerHalf = kT0Count / kSyncHalves;             // 18
 constexpr int kT0PerWaveMax = (kT0PerHalf + kSyncWaves - 1) / kSyncWaves;   // 3 (waves get 2 or 3 time offsets)
-constexpr int kSublistCap = kT0PerWaveMax * kF0Count;          // 747 entries, worst case
+constexpr int kSublistCap = (kT0PerWaveMax * kF0Count + 3) & ~3; // 748: the worst case (747 entries) rounded up so that every sub-list starts 16-byte aligned
 constexpr int kSublistsPerFrame = kSegments * kSyncHalves * kSyncWaves;     // 64, in scan order: segment, half, wave
 constexpr int kScoresPerFrame = kSegments * kT0Count * kF0Count; // 35856
 
@@ -45,7 +45,7 @@ hipError_t launch_waterfall(const float *iq, uint8_t *mag, const Ft8Tables *tab,
 hipError_t launch_sync(const uint8_t *mag, uint32_t *lists, int32_t *list_counts, int16_t *score_map,
                        int nframes, int min_score, hipStream_t s);
 hipError_t launch_heap(const uint32_t *lists, const int32_t *list_counts, ft8gpu_candidate *cands,
-                       int32_t *counts, int nframes, int max_candidates, hipStream_t s);
+                       int32_t *counts, int nframes, int max_candidates, hipStream_t s, bool latency_hidden = false);
 hipError_t launch_decode(const uint8_t *mag, const ft8gpu_candidate *cands, const int32_t *counts,
                          ft8gpu_decode_status *status, int nframes, int max_candidates, int ldpc_iters,
                          bool count_errors, int force_ieee_div, hipStream_t s);

@@ -16,6 +16,7 @@
 //                    wave per frame with the heap in LDS, so that candidate order is bit-identical
 //                    to ft8_find_sync().
 #include "ft8gpu_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -443,6 +444,108 @@ __device__ __forceinline__ void heap_select_regs(const uint32_t *__restrict__ fr
     if (2 * lane + 1 < max_candidates) out[2 * lane + 1] = 2 * lane + 1 < heap_size ? ent[h.kO & 0xFFFFu] : 0ull;
 }
 
+// ---- the same replay, one LANE per frame (large launches, candidate caps up to 128) ------------------------------------
+// The forms above give a frame a whole wave: 64 entries are prefiltered at once, but the replay itself runs on one
+// lane (or on the scalar unit), so every one of its instructions occupies a 64-lane issue slot for one frame -- about
+// 16 000 VALU instructions per frame, 3 % of all VALU instructions of a batch, spent beside the VALU-bound LDPC kernel.
+// Here each lane replays the heap of its own frame with the plain reference algorithm; control flow diverges between
+// lanes, but every issued instruction now works for up to 64 frames.  A heap entry is one 32-bit word -- score (16
+// bits, signed) | segment (2) | time-offset index (6) | frequency offset (8) -- so that comparisons read one word and
+// the heap of a lane is max_candidates words, stored element-major ([element][lane]: lanes touching the same element,
+// the common case, hit 64 different banks).  List entries are read four at a time (every sub-list is 16-byte aligned).
+// Same insertion / eviction / heapify / heap-sort rules in the same order: identical candidate lists.
+__device__ __forceinline__ int sk(uint32_t key) { return (int)key >> 16; }
+
+__global__ __launch_bounds__(64)
+void ft8_heap_simt_kernel(const uint32_t *__restrict__ lists, const int32_t *__restrict__ list_counts,
+                          ft8gpu_candidate *__restrict__ cands, int32_t *__restrict__ counts, int nframes, int max_candidates) {
+    extern __shared__ uint32_t s_keys[];                          // [max_candidates][64]
+    const int lane = threadIdx.x;
+    const int frame = blockIdx.x * 64 + lane;
+    if (frame >= nframes) return;                                // (no barrier in this kernel)
+    uint32_t *h = s_keys + lane;                                 // element i of this lane: h[64 * i]
+    const int cap = max_candidates;
+    int heap_size = 0;
+
+    auto down = [&](int size) {                                  // heapify_down from the root
+        int current = 0;
+        const uint32_t cur = h[0];
+        while (true) {
+            int smallest = current;
+            uint32_t sv = cur;
+            const int left = 2 * current + 1, right = left + 1;
+            if (left < size) { const uint32_t l = h[64 * left]; if (sk(l) < sk(sv)) { smallest = left; sv = l; } }
+            if (right < size) { const uint32_t r = h[64 * right]; if (sk(r) < sk(sv)) { smallest = right; sv = r; } }
+            if (smallest == current) break;
+            h[64 * current] = sv;
+            current = smallest;
+        }
+        h[64 * current] = cur;
+    };
+    auto up = [&](int size) {                                    // heapify_up from the last node
+        int current = size - 1;
+        const uint32_t cur = h[64 * current];
+        while (current > 0) {
+            const int parent = (current - 1) / 2;
+            const uint32_t pv = h[64 * parent];
+            if (sk(cur) >= sk(pv)) break;
+            h[64 * current] = pv;
+            current = parent;
+        }
+        h[64 * current] = cur;
+    };
+
+    const uint32_t *fl = lists + (size_t)frame * kSublistsPerFrame * kSublistCap;
+    const int32_t *fc = list_counts + (size_t)frame * kSublistsPerFrame;
+    int root_score = 0;                                          // score of h[0] while the heap is full
+    for (int sub = 0; sub < kSublistsPerFrame; ++sub) {          // (time_sub, freq_sub, time_offset) order
+        const int n = fc[sub];
+        const uint32_t seg_bits = (uint32_t)(sub / (kSyncHalves * kSyncWaves)) << 14;
+        const uint4 *src = reinterpret_cast<const uint4 *>(fl + (size_t)sub * kSublistCap);
+        for (int e0 = 0; e0 < n; e0 += 4) {
+            const uint4 v4 = src[e0 >> 2];
+            const uint32_t vs[4] = { v4.x, v4.y, v4.z, v4.w };
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (e0 + j >= n) break;
+                const uint32_t key = (vs[j] & 0xFFFF3FFFu) | seg_bits;       // t0 index < 36: bits 14, 15 of the list entry are free
+                const int score = sk(key);
+                if (heap_size == cap) {
+                    if (!(score > root_score)) continue;                     // the common case once the heap is full
+                    h[0] = h[64 * (heap_size - 1)];
+                    --heap_size;
+                    down(heap_size);
+                }
+                h[64 * heap_size] = key;
+                ++heap_size;
+                up(heap_size);
+                if (heap_size == cap) root_score = sk(h[0]);
+            }
+        }
+    }
+    // heap sort (descending)
+    for (int len = heap_size; len > 1;) {
+        const uint32_t tmp = h[64 * (len - 1)];
+        h[64 * (len - 1)] = h[0];
+        h[0] = tmp;
+        --len;
+        down(len);
+    }
+    counts[frame] = heap_size;
+    uint64_t *out = reinterpret_cast<uint64_t *>(cands) + (size_t)frame * max_candidates;
+    for (int i = 0; i < max_candidates; ++i) {
+        uint64_t c = 0;                                                      // deterministic tail
+        if (i < heap_size) {
+            const uint32_t key = h[64 * i];
+            const uint32_t seg = (key >> 14) & 3u;
+            const uint32_t t0 = (uint32_t)((int)((key >> 8) & 0x3Fu) + kT0Min) & 0xFFFFu;
+            c = (uint64_t)(key >> 16) | ((uint64_t)t0 << 16) | ((uint64_t)(key & 0xFFu) << 32) |
+                ((uint64_t)(seg >> 1) << 48) | ((uint64_t)(seg & 1u) << 56);
+        }
+        out[i] = c;
+    }
+}
+
 __global__ __launch_bounds__(256)
 void ft8_heap_kernel(const uint32_t *__restrict__ lists, const int32_t *__restrict__ list_counts,
                      ft8gpu_candidate *__restrict__ cands, int32_t *__restrict__ counts,
@@ -539,8 +642,18 @@ hipError_t launch_sync(const uint8_t *mag, uint32_t *lists, int32_t *list_counts
 }
 
 hipError_t launch_heap(const uint32_t *lists, const int32_t *list_counts, ft8gpu_candidate *cands,
-                       int32_t *counts, int nframes, int max_candidates, hipStream_t s) {
+                       int32_t *counts, int nframes, int max_candidates, hipStream_t s, bool latency_hidden) {
     if (nframes < 1) return hipSuccess;
+    // One lane per frame (ft8_heap_simt_kernel) issues a tenth of the instructions but takes about 0.55 ms whatever the
+    // number of frames (0.1-0.3 ms for the forms below): the batch pipeline asks for it when the kernels it runs beside
+    // are long enough to cover that (latency_hidden), everybody else gets the short chain.
+    // (FT8GPU_HEAP_SIMT=0 never, =2 whenever the cap allows: the parity test of this form)
+    static const int simt = [] { const char *e = getenv("FT8GPU_HEAP_SIMT"); return e ? atoi(e) : 1; }();
+    if (max_candidates <= 128 && ((simt == 1 && latency_hidden && nframes >= 256) || simt == 2)) {
+        hipLaunchKernelGGL(ft8_heap_simt_kernel, dim3((nframes + 63) / 64), dim3(64), (size_t)max_candidates * 64 * sizeof(uint32_t), s,
+                           lists, list_counts, cands, counts, nframes, max_candidates);
+        return hipGetLastError();
+    }
     const size_t lds = (size_t)4 * (max_candidates + 64) * sizeof(uint64_t);
     // Two forms of the same replay.  The register form has the shorter dependent chain (a frame takes about
     // 0.11 ms instead of 0.14) and is what small launches wait for; it issues more instructions, though, and a

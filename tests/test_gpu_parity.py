@@ -800,3 +800,36 @@ def test_gpu_against_the_independent_numpy_restatement(gpu_decoder, frames, orac
             assert (int(st[c]["ldpc_errors"]), int(st[c]["iters"]), bytes(st[c]["a91"])) == (errors, entered, a91), (k, c)
             checked += 1
     assert checked > 40
+
+
+def test_heap_one_lane_per_frame_form_is_exact(oracle):
+    """ft8_heap_simt_kernel (one lane per frame; the batch pipeline uses it from 3072 frames on) must return the
+    reference's candidate lists -- order included -- like the wave-per-frame forms: forced for every launch in a child
+    process (FT8GPU_HEAP_SIMT=2) and compared with the oracle at several caps, thresholds and ragged frame counts"""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.path.join(os.environ["FT8_ROOT"], "tests")); sys.path.insert(0, os.environ["FT8_ROOT"])
+import oracle_lib, synth_util as S, rtlsdr_ft8d_amd as ft8
+oracle_lib.lib()
+enc = S.oracle_encode_fn(oracle_lib)
+frames = [np.stack(oracle_lib.selftest_signal())] + [S.make_frame(s, n, enc, snr_range=(-20, 0))[0] for s, n in ((3, 5), (4, 30), (5, 60), (6, 0), (7, 45))]
+frames.append(np.zeros((2, 48000), np.float32))
+rng = np.random.default_rng(9)
+mags = [oracle_lib.waterfall(f[0], f[1]) for f in frames] + [rng.integers(0, 256, 94208, dtype=np.uint8) for _ in range(70)]   # 77 frames: two waves, ragged
+mag = np.stack(mags)
+bad = []
+with ft8.Decoder(device=0, max_frames=len(mags)) as d:
+    for cap, ms in ((120, 10), (128, 10), (7, 10), (1, 10), (33, 0), (120, -5), (64, 30)):
+        d.set_params(min_score=ms, max_candidates=cap)
+        cands, counts = d.find_sync(mag)
+        for k in range(len(mags)):
+            ref = oracle_lib.find_sync(mags[k], cap, ms)
+            if counts[k] != len(ref) or not np.array_equal(cands[k, :counts[k]], ref) or cands[k, counts[k]:].tobytes().strip(b"\0"):
+                bad.append((cap, ms, k))
+print("RESULT", bad[:5], len(bad))
+'''
+    env = dict(os.environ, FT8GPU_HEAP_SIMT="2", FT8_ROOT=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert "RESULT [] 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
