@@ -30,10 +30,10 @@ def csrc_hash():
                 h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
 
-KERNELS = ("ft8_decode_kernel", "ft8_waterfall_kernel", "ft8_sync_kernel", "ft8_heap_kernel", "ft8_spots_kernel",
+KERNELS = ("ft8_decode_kernel", "ft8_waterfall_kernel", "ft8_sync_kernel", "ft8_heap_simt_kernel", "ft8_heap_kernel", "ft8_spots_kernel",
            "ft8_synth_kernel", "ft8_rx_block_kernel")
 WIDE = {"waterfall", "sync", "rx_block"}
-HALF_BATCH = {"waterfall", "sync", "heap", "decode", "spots"}      # two launches per batch (a small first part and the rest): the mean per launch covers half a batch
+HALF_BATCH = {"waterfall", "sync", "heap", "heap_simt", "decode", "spots"}      # two launches per batch (a small first part and the rest): the mean per launch covers half a batch
 
 
 def short(name):
