@@ -77,6 +77,12 @@ __device__ __forceinline__ float div_one_5(float a, float b) {
 // As the compiler writes it this is v_cmp + v_bfi + v_cndmask per value.  Here the compare narrows EXEC itself
 // (v_cmpx) and the copysign is written in place under that mask: one VALU instruction less per value -- nine per BP
 // iteration -- for two scalar moves that save and restore EXEC (the scalar unit has the slack).
+// Hazard note: v_cmpx is a VALU write of EXEC, and gfx9 wants 5 wait states between such a write and a DPP
+// instruction; the compiler's hazard recogniser cannot see into an asm block.  The blocks below are followed by the
+// tanh results' LDS stores in the BP loop, never by DPP code (wave_sum / wave_xor sit in the prologue and epilogue);
+// tools/kernel_resources.py scans the compiled kernels for a DPP instruction within 5 wait states of a v_cmpx and
+// tests/test_kernel_resources.py fails the build if one ever appears.  (A blanket `s_nop 4` behind each block would
+// cost about 2 % of the loop.)
 __device__ __forceinline__ float clamp_497(float q, float x) {
     unsigned long long saved;
     asm("s_mov_b64 %1, exec\n\t"
@@ -115,6 +121,18 @@ __device__ __forceinline__ float tanh_one(float x) {
     const float a = x * (945.0f + x2 * (105.0f + x2));
     const float b = 945.0f + x2 * (420.0f + x2 * 15.0f);
     return clamp_497(FAST ? div_one_5(a, b) : __fdiv_rn(a, b), x);
+}
+
+// fast_tanh() exactly as ft8_lib writes it -- plain compares, plain IEEE division, no inline assembly: what the
+// exhaustive self-test holds BOTH kernel forms against (so the EXEC-narrowing clamp itself is checked on all 2^32
+// inputs, not only the division chain)
+__device__ __forceinline__ float tanh_ref(float x) {
+    if (x < -4.97f) return -1.0f;
+    if (x > 4.97f) return 1.0f;
+    const float x2 = x * x;
+    const float a = x * (945.0f + x2 * (105.0f + x2));
+    const float b = 945.0f + x2 * (420.0f + x2 * 15.0f);
+    return __fdiv_rn(a, b);
 }
 
 // ---- fast_atanh() of ft8_lib ldpc.c

@@ -31,8 +31,10 @@ __global__ __launch_bounds__(256) void bp_math_exhaustive(Counts *out, uint32_t 
         const bool in_a = (ax == 0.0f || ax >= bpm::kAtanhMinAbs) && ax <= bpm::kAtanhMaxAbs;
         if (in_t) {
             ++ti;
-            const float f = bpm::tanh_one<true>(x), r = bpm::tanh_one<false>(x);
-            if (!same(f, r)) { ++tm; bad = bits; }
+            // r: the reference's own expression (compares + IEEE division, no assembly); f, g: the kernel's two forms,
+            // both of which go through the EXEC-narrowing clamp
+            const float f = bpm::tanh_one<true>(x), g = bpm::tanh_one<false>(x), r = bpm::tanh_ref(x);
+            if (!same(f, r) || !same(g, r)) { ++tm; bad = bits; }
             tmax = max(tmax, __float_as_uint(__builtin_fabsf(r)));
         }
         if (in_a) {
@@ -45,8 +47,9 @@ __global__ __launch_bounds__(256) void bp_math_exhaustive(Counts *out, uint32_t 
         const bool y_t = (ay == ay) && (ay == 0.0f || ay >= bpm::kTanhMinAbs);
         const bool y_a = (ay == ay) && (ay == 0.0f || ay >= bpm::kAtanhMinAbs) && ay <= bpm::kAtanhMaxAbs;
         if (in_t && y_t) {
-            const bpm::f2 f = bpm::tanh_pair<true>(bpm::f2{ x, y }), r = bpm::tanh_pair<false>(bpm::f2{ x, y });
-            if (!same(f.x, r.x) || !same(f.y, r.y)) { ++pm; bad = bits; }
+            const bpm::f2 f = bpm::tanh_pair<true>(bpm::f2{ x, y }), g = bpm::tanh_pair<false>(bpm::f2{ x, y });
+            const float rx = bpm::tanh_ref(x), ry = bpm::tanh_ref(y);
+            if (!same(f.x, rx) || !same(f.y, ry) || !same(g.x, rx) || !same(g.y, ry)) { ++pm; bad = bits; }
         }
         if (in_a && y_a) {
             const bpm::f2 f = bpm::atanh_pair<true>(bpm::f2{ y, x }), r = bpm::atanh_pair<false>(bpm::f2{ y, x });

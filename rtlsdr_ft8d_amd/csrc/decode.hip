@@ -32,6 +32,7 @@
 #include "ft8_tables.h"
 #include "unpack_dev.h"
 #include "bp_math.h"
+#include <stddef.h>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -495,47 +496,50 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
         if (lane < 13 && ((B1 >> lane) & 1ull)) c ^= d_tab.crc_bit[64 + lane];
         crc_calc = wave_xor(c);
     }
-    if (lane == 0) {
-        ft8gpu_decode_status st;
-        st.ldpc_errors = (int16_t)min_errors;
-        st.iters = (int16_t)iter;
-        st.crc_extracted = 0;
-        st.crc_calculated = 0;
-        st.unpack_status = 0;
-        st.ok = 0;
-        st.pad = 0;
-        for (int i = 0; i < 25; ++i) st.text[i] = 0;
-        // codeword bit i is bit (i & 63) of B{i >> 6}; packed MSB first
-        const uint64_t w0 = __brevll(B0);                         // bits 0..63, MSB first
-        const uint64_t w1 = __brevll(B1) & 0xFFFFFFE000000000ull; // bits 64..90
-        uint8_t a91[12];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a91[i] = (uint8_t)(w0 >> (56 - 8 * i));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a91[8 + i] = (uint8_t)(w1 >> (56 - 8 * i));
-#pragma unroll
-        for (int i = 0; i < 12; ++i) st.a91[i] = a91[i];
-        if (min_errors == 0) {
-            st.crc_extracted = (uint16_t)(((a91[9] & 0x07) << 11) | (a91[10] << 3) | (a91[11] >> 5));
-            a91[9] &= 0xF8;
-            a91[10] = 0;
-            a91[11] = 0;
-            st.crc_calculated = (uint16_t)crc_calc;
-            if (st.crc_extracted == st.crc_calculated) {
-                const int rc = ft8dev::unpack77(a91, st.text);
-                st.unpack_status = (int8_t)rc;
-                st.ok = rc >= 0 ? 1 : 0;
-                if (rc < 0) for (int i = 0; i < 25; ++i) st.text[i] = 0;
+    // The 48-byte record is composed in the wave's LDS tile (the LLR area is free now) and leaves as one contiguous
+    // 12-dword burst.  Nothing of it lives in private memory: min_errors, iter and the ballot words are wave-uniform
+    // scalars, the bytes of a91 are shifts of two 64-bit words, and unpack77 works on those words and on a work area
+    // behind the record -- the kernel has no scratch segment (tools/isa_census.py and tests/test_abi.py check it).
+    static_assert(sizeof(ft8gpu_decode_status) == 48, "record is 12 dwords");
+    static_assert(offsetof(ft8gpu_decode_status, a91) == 10 && offsetof(ft8gpu_decode_status, text) == 22, "record layout");
+    uint32_t *rec32 = reinterpret_cast<uint32_t *>(llr);
+    char *rec = reinterpret_cast<char *>(llr);
+    // codeword bit i is bit (i & 63) of B{i >> 6}; packed MSB first
+    const uint64_t w0 = __brevll(B0);                                 // bits 0..63, MSB first
+    const uint64_t w1 = __brevll(B1) & 0xFFFFFFE000000000ull;         // bits 64..90
+    if (lane < 12) {
+        // dwords 0..5 hold the fixed fields and a91 (bytes 10..21), the rest is text / pad: zero
+        const uint32_t hi0 = (uint32_t)(w0 >> 32), lo0 = (uint32_t)w0, hi1 = (uint32_t)(w1 >> 32);
+        // a91[k] = byte k of (w0, w1) in big-endian order; record byte 10 + k
+        uint32_t v = 0;
+        if (lane == 0) v = ((uint32_t)min_errors & 0xFFFFu) | ((uint32_t)iter << 16);
+        else if (lane == 2) v = (__builtin_bswap32(hi0) & 0xFFFFu) << 16;                                    // a91[0..1]
+        else if (lane == 3) v = (__builtin_bswap32(hi0) >> 16) | (__builtin_bswap32(lo0) << 16);              // a91[2..5]
+        else if (lane == 4) v = (__builtin_bswap32(lo0) >> 16) | (__builtin_bswap32(hi1) << 16);              // a91[6..9]
+        else if (lane == 5) v = __builtin_bswap32(hi1) >> 16;                                                 // a91[10..11]
+        rec32[lane] = v;
+    }
+    if (min_errors == 0) {                                            // wave-uniform
+        const uint32_t crc_extracted = (uint32_t)(w1 >> 37) & 0x3FFFu;   // bits 77..90
+        if (lane == 0) {
+            rec32[1] = crc_extracted | (crc_calc << 16);
+            if (crc_extracted == crc_calc) {
+                ft8dev::UnpackWork *wk = reinterpret_cast<ft8dev::UnpackWork *>(rec + 64);
+                const int rc = ft8dev::unpack77(w0, w1 & 0xFFF8000000000000ull, rec + offsetof(ft8gpu_decode_status, text), wk);
+                if (rc < 0) {
+                    // a failed unpack may have left characters behind: text is all zeros unless ok
+                    rec32[5] &= 0xFFFFu;
+                    for (int i = 6; i < 12; ++i) rec32[i] = 0;
+                }
+                rec[offsetof(ft8gpu_decode_status, unpack_status)] = (char)rc;
+                rec[offsetof(ft8gpu_decode_status, ok)] = rc >= 0 ? 1 : 0;
+                rec[offsetof(ft8gpu_decode_status, pad)] = 0;
             }
         }
-        // stage the 48-byte record in LDS (the LLR area is free now) ...
-        *reinterpret_cast<ft8gpu_decode_status *>(llr) = st;
     }
-    // ... and store it as one contiguous 12-dword burst instead of lane 0's scattered narrow stores
     wave_lds_sync();
-    static_assert(sizeof(ft8gpu_decode_status) == 48, "record is 12 dwords");
     if (lane < 12)
-        reinterpret_cast<uint32_t *>(status + (size_t)frame * max_candidates + ci)[lane] = reinterpret_cast<const uint32_t *>(llr)[lane];
+        reinterpret_cast<uint32_t *>(status + (size_t)frame * max_candidates + ci)[lane] = rec32[lane];
 }
 
 }  // namespace

@@ -631,8 +631,14 @@ private:
                 q_.pop_front();
             }
             job.first();
-            { std::lock_guard<std::mutex> g(job.second->m); --job.second->pending; }
-            job.second->cv.notify_all();
+            // The latch lives on the caller's stack (run_shards): the waiter may return, and its frame may die, as soon as
+            // it can observe pending == 0 -- which needs the mutex.  So the notification is sent while the mutex is still
+            // held; after the unlock this thread never touches the latch again.
+            {
+                std::lock_guard<std::mutex> g(job.second->m);
+                --job.second->pending;
+                job.second->cv.notify_all();
+            }
         }
     }
     std::mutex m_;
@@ -830,8 +836,9 @@ extern "C" int ft8gpu_gather_spots(ft8gpu_ctx *const *ctxs, int ndev, const stru
 }
 
 extern "C" void ft8gpu_gather_shutdown(void) {
-    Rccl *r = rccl();
     std::lock_guard<std::mutex> lock(g_gather_mu);
+    if (g_groups.empty()) return;                   // no gather was ever performed: nothing to destroy, and librccl is NOT loaded for this
+    Rccl *r = rccl();                               // a group exists, so the library is already bound: this only returns the handle
     for (GatherGroup *grp : g_groups) {
         if (r->lib) for (ncclComm_t c : grp->comms) if (c) (void)r->CommDestroy(c);
         delete grp;

@@ -1,6 +1,6 @@
 """GPU tests at the sizes of BASELINE.json's configs, through size-independent properties
 (determinism, batch-composition independence, permutation equivariance, planted-signal recall,
-checksums) plus the CPU oracle on samples."""
+checksums) and against the CPU oracle on EVERY frame of configs[2] and configs[4]."""
 import hashlib
 
 import numpy as np
@@ -17,6 +17,29 @@ def _synth(ft8, workload, dec, first, n, nsig, snr, pool_tones, seed_off=0):
     return iq, sig, picks
 
 
+def _host_threads():
+    """host cores the oracle may use for the full-size comparisons (affinity mask capped by the cgroup quota)"""
+    import bench
+    return bench.usable_cores()
+
+
+def _oracle_all(oracle, iq_dev, params=None, chunk=1024):
+    """the CPU oracle on EVERY frame of a device batch (OpenMP over frames; D2H in chunks of 393 MB)"""
+    decs, ns = [], []
+    nt = _host_threads()
+    for f0 in range(0, iq_dev.shape[0], chunk):
+        d, n = oracle.subsystem_batch(iq_dev[f0:f0 + chunk].cpu().numpy(), params, nthreads=nt)
+        decs.append(d)
+        ns.append(n)
+    return np.concatenate(decs), np.concatenate(ns)
+
+
+def _assert_frames_equal(got, got_n, ref, ref_n, what):
+    """counts and the used record slots byte for byte (unused slots are zero on both sides: both start from zeros)"""
+    bad = [f for f in range(len(ref_n)) if got_n[f] != ref_n[f] or got[f].tobytes() != ref[f].tobytes()]
+    assert not bad, f"{what}: {len(bad)} of {len(ref_n)} frames differ from the oracle, first {bad[:8]}"
+
+
 def _decode_dev(ft8, dec, iq, n):
     import torch
     spots = torch.zeros((n, ft8.MAX_MESSAGES * 28), dtype=torch.uint8, device="cuda")
@@ -28,7 +51,7 @@ def _decode_dev(ft8, dec, iq, n):
 
 
 def test_config3_full_batch_properties(oracle):
-    """configs[2]: 4096 synthetic frames, full pipeline on one GPU"""
+    """configs[2]: 4096 synthetic frames, full pipeline on one GPU; all 4096 frames against the oracle"""
     import torch
     import rtlsdr_ft8d_amd as ft8
     from rtlsdr_ft8d_amd import workload
@@ -58,7 +81,8 @@ def test_config3_full_batch_properties(oracle):
         host_all = iq[:hn].cpu().numpy()
         dh, nh = dec.decode_batch(host_all)
         assert np.array_equal(nh, n1[:hn]) and dh.tobytes() == d1[:hn].tobytes()
-        host_iq = host_all[:24]
+        # the oracle on EVERY frame of the batch (round 3 sampled 24): about 2 s of 16 host cores on the box
+        rdec, rn = _oracle_all(oracle, iq)
     # recall / false decodes against what was planted
     found = planted = false_calls = total_calls = 0
     for f in range(B):
@@ -72,10 +96,7 @@ def test_config3_full_batch_properties(oracle):
     assert n1.sum() > 8 * B                         # the batch really decodes (about 12 messages per frame)
     assert found >= 0.75 * planted                  # strong planted signals are recovered (collisions cost some)
     assert false_calls <= 1e-3 * total_calls + 2    # CRC-14 false decodes are rare
-    # oracle on a sample of the very same frames
-    for f in range(host_iq.shape[0]):
-        rdec, rn = oracle.subsystem(host_iq[f, 0], host_iq[f, 1])
-        assert n1[f] == rn and d1[f].tobytes() == rdec.tobytes()
+    _assert_frames_equal(d1, n1, rdec, rn, "configs[2], 4096 frames")
 
 
 def test_config2_gpu_waterfall_sync_cpu_ldpc(oracle):
@@ -100,8 +121,8 @@ def test_config2_gpu_waterfall_sync_cpu_ldpc(oracle):
 
 def test_config5_oversubscribed_candidates(oracle):
     """configs[4] at SURVEY.md 8(d)'s size: 1024 frames, K_MAX_CANDIDATES x 4, 60 weak signals per frame --
-    stresses heap eviction and BP occupancy.  Full size through determinism and sub-batch independence,
-    stage boundaries and the whole path against the oracle on samples."""
+    stresses heap eviction and BP occupancy.  Full size through determinism and sub-batch independence, the whole
+    path against the oracle on ALL 1024 frames, the candidate lists on a sample."""
     import rtlsdr_ft8d_amd as ft8
     from rtlsdr_ft8d_amd import workload
     B, S = 1024, 60
@@ -118,14 +139,14 @@ def test_config5_oversubscribed_candidates(oracle):
         mag = dec.waterfall(host_iq)
         cands, counts = dec.find_sync(mag)
         gdec, gn = dec.decode_batch(host_iq)
+        p = oracle.default_params(10, 480, 20)
+        rdec_all, rn_all = _oracle_all(oracle, iq, p)        # every one of the 1024 frames (round 3 sampled 32)
     assert counts.max() > 120                                # the cap of 120 would have been exceeded
     assert np.array_equal(gn, n1[sample]) and gdec.tobytes() == d1[sample].tobytes()
-    p = oracle.default_params(10, 480, 20)
-    for j in range(len(sample)):
+    _assert_frames_equal(d1, n1, rdec_all, rn_all, "configs[4], 1024 frames at cap 480")
+    for j in range(len(sample)):                             # stage boundary on the sample: the candidate lists themselves
         rc = oracle.find_sync(mag[j], 480, 10)
         assert counts[j] == len(rc) and np.array_equal(cands[j, :counts[j]], rc)
-        rdec, rn = oracle.subsystem(host_iq[j, 0], host_iq[j, 1], p)
-        assert gn[j] == rn and gdec[j].tobytes() == rdec.tobytes()
 
 
 def test_non_overlapped_pipeline_gives_the_same_records(oracle):

@@ -1,0 +1,31 @@
+"""No kernel of libft8gpu.so may use scratch memory, and nothing may follow bp_math.h's EXEC-narrowing assembly too
+closely (CPU box: hipcc cross-compiles gfx950 without a GPU).  tools/kernel_resources.py does the work: it compiles
+every csrc/*.hip to assembly with the product's flags and reads the kernels' metadata.
+
+Round 3's LDPC kernel had a 128-byte scratch segment (the status record and unpack77's byte buffers were indexed
+dynamically in private memory) and wrote 5.8 x the bytes of its own records to HBM because of it; round 4 composes
+the record in LDS.  This test keeps it that way."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_no_kernel_uses_scratch_and_no_dpp_follows_a_cmpx(tmp_path):
+    out = tmp_path / "res.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), "--json", str(out)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.load(open(out))
+    assert d["problems"] == []
+    ks = {k["kernel"]: k for k in d["kernels"]}
+    # the kernels of the hot path are all there, and the LDPC kernel keeps eight waves per SIMD
+    for name in ("ft8_waterfall_kernel_v2<false>", "ft8_sync_kernel<false>", "ft8_heap_kernel", "ft8_heap_simt_kernel",
+                 "ft8_decode_kernel<false, 3>", "ft8_decode_kernel<true, 1>", "ft8_spots_kernel"):
+        assert name in ks, (name, sorted(ks))
+        assert ks[name]["scratch_bytes_per_lane"] == 0
+    assert ks["ft8_decode_kernel<false, 3>"]["waves_per_simd_by_vgprs"] == 8
+    assert ks["ft8_decode_kernel<false, 3>"]["sgprs"] <= 80          # 256-thread workgroups: 8 per CU only up to 80 SGPRs
+    assert ks["ft8_waterfall_kernel_v2<false>"]["waves_per_simd_by_vgprs"] >= 4

@@ -149,11 +149,16 @@ def main():
     # The compiler lays the loop out as [ieee atanh][fast atanh][hard decision + screen, copy 1][ieee tanh]
     # [hard decision + screen, copy 2][fast tanh][row products, guard].  A block without a division belongs to the
     # stream of the next division block in layout order; the blocks behind the last one are common to both streams.
+    # (Since round 4 the compiler rotates the loop and puts the row products and the guard at its TOP: the blocks in front
+    # of the first division block are common too -- whichever rotation is chosen, an iteration is
+    # [atanh][hard decision + screen][tanh] per stream plus one common part at either end.)
+    first_div = next((i for i, r in enumerate(rows) if r["stream"] in ("fast", "ieee")), len(rows))
     nxt = None
-    for r in reversed(rows):
+    for i in range(len(rows) - 1, -1, -1):
+        r = rows[i]
         if r["stream"] in ("fast", "ieee"):
             nxt = r["stream"]
-        elif nxt is not None and r["n"] > 0:
+        elif nxt is not None and r["n"] > 0 and i > first_div:
             r["stream"] = nxt + "*"                       # attributed copy
         else:
             r["stream"] = "common"
