@@ -92,6 +92,8 @@ def parse_args(argv=None):
                          "reach its sustained clock (per-step times from cold: 5.65, 4.82, 4.67, 4.54, 4.48, 4.38, 4.25, 4.25 ... ms, "
                          "tools/perstep_probe.py), which short --warmup values would put inside the timed region; reported in the line")
     ap.add_argument("--no-clock-sampler", action="store_true", help="do not poll the GPU's sysfs clock / power files during the timed region")
+    ap.add_argument("--debug-flags", type=int, default=0,
+                    help="FT8GPU_DBG_* bits for the decoder context (profiling of the non-product kernel forms; reported in the line, 0 = product)")
     ap.add_argument("--shards", type=int, default=8, help="configs[3] on one GPU: number of contexts / shards")
     return ap.parse_args(argv)
 
@@ -300,6 +302,9 @@ def main():
     dec = None
     if not (args.config == 3 and world == 1):
         dec = ft8.Decoder(device=local_rank, max_frames=B, min_score=10, max_candidates=maxc, ldpc_iters=20)
+        if args.debug_flags:
+            dec.set_debug_flags(args.debug_flags)
+            out["debug_flags"] = args.debug_flags           # not the product configuration
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -10,11 +10,9 @@
  *   A batch is `nframes` such frames back to back: iq[nframes][2][48000].
  *   waterfall = uint8 mag[92][2][2][256] (block, time_sub, freq_sub, bin) = 94208 bytes per frame.
  *
- * Environment: FT8GPU_DEVICE=<n> GPU used by the drop-in ft8_subsystem (default 0).  The test hooks are
- * per-context flags (ft8gpu_set_debug_flags); FT8GPU_OVERLAP=0, FT8GPU_FORCE_IEEE_DIV=1 and
- * FT8GPU_DECODE_PIPELINE_FORM=1 only set their initial value for contexts created afterwards.
- * FT8GPU_WATERFALL_FORM=1 / FT8GPU_WATERFALL_STAGE4=quad select the other (bit-identical) forms of the waterfall kernel,
- * read once per process.
+ * Environment: FT8GPU_DEVICE=<n> is the GPU used by the drop-in ft8_subsystem (default 0; the reference's function has no
+ * device argument).  Nothing else is read from the environment: every test hook and every alternative kernel form is a
+ * per-context flag (ft8gpu_set_debug_flags), so that behaviour never depends on the process environment.
  */
 #ifndef FT8GPU_H
 #define FT8GPU_H
@@ -133,6 +131,13 @@ void *ft8gpu_get_stream(ft8gpu_ctx *ctx);
 #define FT8GPU_DBG_PIPELINE_FORM  2u  /* ft8gpu_decode_candidates runs the form of the LDPC kernel ft8gpu_decode_batch
                                          uses (no exact error count: ldpc_errors is 0 or 83) */
 #define FT8GPU_DBG_NO_OVERLAP     4u  /* one launch per stage for the whole batch: no two-half overlap, no chunked upload */
+/* alternative, bit-identical forms of kernels (the product form is the one with no bit set; DESIGN.md section 4 has
+ * the measurements that picked it).  QUAD and LDS exclude each other, as do the two heap bits. */
+#define FT8GPU_DBG_WATERFALL_QUAD 8u  /* last FFT stage: 4 x 4 transposes inside the quads (DPP selects) instead of across rows */
+#define FT8GPU_DBG_WATERFALL_LDS  16u /* last FFT stage: second exchange through LDS */
+#define FT8GPU_DBG_HEAP_LANE_PER_FRAME 32u  /* heap replay: one lane per frame for every launch the cap allows (<= 128) */
+#define FT8GPU_DBG_HEAP_WAVE_PER_FRAME 64u  /* heap replay: one wave per frame for every launch */
+#define FT8GPU_DBG_ALL            127u
 int  ft8gpu_set_debug_flags(ft8gpu_ctx *ctx, unsigned flags);   /* unknown bits are refused */
 /* Proof by exhaustion behind the LDPC kernel's short division chains (csrc/bp_math.h): fast_tanh / fast_atanh of
  * ft8_lib ldpc.c (reached through ft8_decode, rtlsdr_ft8d.c:1476) are functions of one float, so all 2^32 inputs are

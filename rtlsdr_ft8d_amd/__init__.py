@@ -50,6 +50,7 @@ class ReportInfo(C.Structure):
 DATAGRAM_STRIDE = 1408
 STREAM_LEGACY = 1                       # FT8GPU_STREAM_LEGACY (= hipStreamLegacy): the legacy null stream, explicitly
 DBG_FORCE_IEEE_DIV, DBG_PIPELINE_FORM, DBG_NO_OVERLAP = 1, 2, 4      # FT8GPU_DBG_* test hooks (per context)
+DBG_WATERFALL_QUAD, DBG_WATERFALL_LDS, DBG_HEAP_LANE_PER_FRAME, DBG_HEAP_WAVE_PER_FRAME = 8, 16, 32, 64   # other kernel forms
 
 
 class Ft8GpuError(RuntimeError):

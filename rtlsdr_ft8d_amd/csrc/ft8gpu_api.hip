@@ -233,12 +233,12 @@ int run_pipeline_overlapped(ft8gpu_ctx *c, const float *d_iq, int n, struct deco
     // main stream events: 0 wf(A) 1 sync(A) 2 wf(B) 9 sync(B) 3 | 4 decode(A) 5 decode(B) 6 spots(B) 7 | 8 end
     // side stream events: 0 heap(A) 1 | 4 spots(A) 5        side2: 2 heap(B) 3
     t.mark(0);
-    HIP_TRY(launch_waterfall(d_iq, c->d_mag, c->d_tab, n0, c->num_cus, c->stream));
+    HIP_TRY(launch_waterfall(d_iq, c->d_mag, c->d_tab, n0, c->num_cus, c->debug_flags, c->stream));
     t.mark(1);
     HIP_TRY(launch_sync(c->d_mag, c->d_lists, c->d_list_counts, nullptr, n0, p.min_score, c->stream));
     HIP_TRY(hipEventRecord(E[0], c->stream));
     t.mark(2);
-    HIP_TRY(launch_waterfall(d_iq + lo * frame_floats, mag1, c->d_tab, n1, c->num_cus, c->stream));
+    HIP_TRY(launch_waterfall(d_iq + lo * frame_floats, mag1, c->d_tab, n1, c->num_cus, c->debug_flags, c->stream));
     t.mark(9);
     HIP_TRY(launch_sync(mag1, lists1, lc1, nullptr, n1, p.min_score, c->stream));
     HIP_TRY(hipEventRecord(E[1], c->stream));
@@ -252,12 +252,12 @@ int run_pipeline_overlapped(ft8gpu_ctx *c, const float *d_iq, int n, struct deco
     // there the wave-per-frame form (VALU lane moves, short chain) is the better neighbour.  Measured in one session:
     // both wave-per-frame 4.157 ms, both lane-per-frame 4.116, this split 4.096.
     const bool hide = n >= 3072;
-    HIP_TRY(launch_heap(c->d_lists, c->d_list_counts, c->d_cands, c->d_counts, n0, mc, c->side, false));
+    HIP_TRY(launch_heap(c->d_lists, c->d_list_counts, c->d_cands, c->d_counts, n0, mc, c->debug_flags, c->side, false));
     t.mark_side(1);
     HIP_TRY(hipEventRecord(E[2], c->side));
     HIP_TRY(hipStreamWaitEvent(c->side2, E[1], 0));
     t.mark_on(c->side2, 2);
-    HIP_TRY(launch_heap(lists1, lc1, cands1, counts1, n1, mc, c->side2, hide));
+    HIP_TRY(launch_heap(lists1, lc1, cands1, counts1, n1, mc, c->debug_flags, c->side2, hide));
     t.mark_on(c->side2, 3);
     HIP_TRY(hipEventRecord(E[3], c->side2));
     // main stream: decode(A), decode(B), spots(B)
@@ -289,11 +289,11 @@ int run_pipeline(ft8gpu_ctx *c, const float *d_iq, int n, struct decoder_results
     StageTimer t(c);
     const ft8gpu_params &p = c->params;
     t.mark(0);
-    HIP_TRY(launch_waterfall(d_iq, c->d_mag, c->d_tab, n, c->num_cus, c->stream));
+    HIP_TRY(launch_waterfall(d_iq, c->d_mag, c->d_tab, n, c->num_cus, c->debug_flags, c->stream));
     t.mark(1);
     HIP_TRY(launch_sync(c->d_mag, c->d_lists, c->d_list_counts, nullptr, n, p.min_score, c->stream));
     t.mark(2);
-    HIP_TRY(launch_heap(c->d_lists, c->d_list_counts, c->d_cands, c->d_counts, n, p.max_candidates, c->stream));
+    HIP_TRY(launch_heap(c->d_lists, c->d_list_counts, c->d_cands, c->d_counts, n, p.max_candidates, c->debug_flags, c->stream));
     t.mark(3);
     HIP_TRY(launch_decode(c->d_mag, c->d_cands, c->d_counts, c->d_status, n, p.max_candidates, p.ldpc_iters, false, force_ieee(c), c->stream));
     t.mark(4);
@@ -335,11 +335,6 @@ static int create_body(ft8gpu_ctx *c) {
     // (the upload stream of the host-buffer path is created on first use: a context that only sees device pointers
     // keeps its three streams on three hardware queues of their own)
     for (auto &e : c->copied) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    // process-wide defaults of the per-context test hooks (ft8gpu_set_debug_flags overrides them)
-    { const char *e = getenv("FT8GPU_OVERLAP"); if (e && e[0] == '0') c->debug_flags |= FT8GPU_DBG_NO_OVERLAP; }
-    { const char *e = getenv("FT8GPU_FORCE_IEEE_DIV"); if (e && e[0] == '1') c->debug_flags |= FT8GPU_DBG_FORCE_IEEE_DIV; }
-    { const char *e = getenv("FT8GPU_DECODE_PIPELINE_FORM"); if (e && e[0] == '1') c->debug_flags |= FT8GPU_DBG_PIPELINE_FORM; }
-
     Ft8Tables *h = (Ft8Tables *)malloc(sizeof(Ft8Tables));
     if (!h) return fail("out of host memory");
     if (build_tables(h)) { free(h); return -1; }
@@ -448,8 +443,11 @@ int ft8gpu_set_params(ft8gpu_ctx *c, const ft8gpu_params *p) {
 
 int ft8gpu_set_debug_flags(ft8gpu_ctx *c, unsigned flags) {
     CHECK_COMMON(c, 0);
-    if (flags & ~(FT8GPU_DBG_FORCE_IEEE_DIV | FT8GPU_DBG_PIPELINE_FORM | FT8GPU_DBG_NO_OVERLAP))
-        return fail("ft8gpu_set_debug_flags: unknown bits 0x%x", flags & ~(FT8GPU_DBG_FORCE_IEEE_DIV | FT8GPU_DBG_PIPELINE_FORM | FT8GPU_DBG_NO_OVERLAP));
+    if (flags & ~FT8GPU_DBG_ALL) return fail("ft8gpu_set_debug_flags: unknown bits 0x%x", flags & ~FT8GPU_DBG_ALL);
+    if ((flags & FT8GPU_DBG_WATERFALL_QUAD) && (flags & FT8GPU_DBG_WATERFALL_LDS))
+        return fail("ft8gpu_set_debug_flags: FT8GPU_DBG_WATERFALL_QUAD and FT8GPU_DBG_WATERFALL_LDS exclude each other");
+    if ((flags & FT8GPU_DBG_HEAP_LANE_PER_FRAME) && (flags & FT8GPU_DBG_HEAP_WAVE_PER_FRAME))
+        return fail("ft8gpu_set_debug_flags: FT8GPU_DBG_HEAP_LANE_PER_FRAME and FT8GPU_DBG_HEAP_WAVE_PER_FRAME exclude each other");
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->debug_flags = flags;
     return 0;
@@ -856,11 +854,11 @@ int ft8gpu_waterfall(ft8gpu_ctx *c, const float *iq, int nframes, uint8_t *mag, 
     for (int f0 = 0; f0 < nframes; f0 += c->max_frames) {
         const int n = (nframes - f0 < c->max_frames) ? nframes - f0 : c->max_frames;
         if (flags & FT8GPU_DEVICE_PTRS) {
-            HIP_TRY(launch_waterfall(iq + f0 * frame_floats, mag + (size_t)f0 * kMagArray, c->d_tab, n, c->num_cus, c->stream));
+            HIP_TRY(launch_waterfall(iq + f0 * frame_floats, mag + (size_t)f0 * kMagArray, c->d_tab, n, c->num_cus, c->debug_flags, c->stream));
         } else {
             if (!c->d_iq) HIP_TRY(hipMalloc(&c->d_iq, (size_t)c->max_frames * frame_floats * sizeof(float)));
             HIP_TRY(hipMemcpyAsync(c->d_iq, iq + f0 * frame_floats, n * frame_floats * sizeof(float), hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(launch_waterfall(c->d_iq, c->d_mag, c->d_tab, n, c->num_cus, c->stream));
+            HIP_TRY(launch_waterfall(c->d_iq, c->d_mag, c->d_tab, n, c->num_cus, c->debug_flags, c->stream));
             HIP_TRY(hipMemcpyAsync(mag + (size_t)f0 * kMagArray, c->d_mag, (size_t)n * kMagArray, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
         }
@@ -881,7 +879,7 @@ int ft8gpu_find_sync(ft8gpu_ctx *c, const uint8_t *mag, int nframes, ft8gpu_cand
         int32_t *dn = dev ? counts + f0 : c->d_counts;
         if (!dev) HIP_TRY(hipMemcpyAsync(c->d_mag, mag + (size_t)f0 * kMagArray, (size_t)n * kMagArray, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(launch_sync(dm, c->d_lists, c->d_list_counts, nullptr, n, c->params.min_score, c->stream));
-        HIP_TRY(launch_heap(c->d_lists, c->d_list_counts, dc, dn, n, mc, c->stream));
+        HIP_TRY(launch_heap(c->d_lists, c->d_list_counts, dc, dn, n, mc, c->debug_flags, c->stream));
         if (!dev) {
             HIP_TRY(hipMemcpyAsync(cands + (size_t)f0 * mc, dc, (size_t)n * mc * sizeof(ft8gpu_candidate), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipMemcpyAsync(counts + f0, dn, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));

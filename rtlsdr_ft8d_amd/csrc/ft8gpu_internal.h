@@ -29,9 +29,7 @@ constexpr int kLdpcN = 174, kLdpcK = 91, kLdpcM = 83;
 
 // waterfall kernel work decomposition
 constexpr int kWfRowsPerItem = 4;                              // FFT rows per work item
-constexpr int kWfGridPerCu = 12;                               // workgroups launched per CU (3 are resident, LDS-limited)
 constexpr int kWfItemsPerFrame = kRowsPerFrame / kWfRowsPerItem; // 46
-constexpr int kWfSpan = (kWfRowsPerItem - 1) * 256 + kNfft;    // samples staged per item
 
 struct Ft8Tables {                 // device-resident constant tables, built on the host at create()
     float  hann[kNfft];            // rtlsdr_ft8d.c:331-334 (sine window)
@@ -40,12 +38,14 @@ struct Ft8Tables {                 // device-resident constant tables, built on 
 };
 
 // kernel launchers (each enqueues on `s`, returns hipGetLastError())
+// debug_flags: the context's FT8GPU_DBG_* bits (kernel-form selectors are read by the launcher that owns the form)
 hipError_t launch_waterfall(const float *iq, uint8_t *mag, const Ft8Tables *tab, int nframes,
-                            int num_cus, hipStream_t s);
+                            int num_cus, unsigned debug_flags, hipStream_t s);
 hipError_t launch_sync(const uint8_t *mag, uint32_t *lists, int32_t *list_counts, int16_t *score_map,
                        int nframes, int min_score, hipStream_t s);
 hipError_t launch_heap(const uint32_t *lists, const int32_t *list_counts, ft8gpu_candidate *cands,
-                       int32_t *counts, int nframes, int max_candidates, hipStream_t s, bool latency_hidden = false);
+                       int32_t *counts, int nframes, int max_candidates, unsigned debug_flags, hipStream_t s,
+                       bool latency_hidden = false);
 hipError_t launch_decode(const uint8_t *mag, const ft8gpu_candidate *cands, const int32_t *counts,
                          ft8gpu_decode_status *status, int nframes, int max_candidates, int ldpc_iters,
                          bool count_errors, int force_ieee_div, hipStream_t s);

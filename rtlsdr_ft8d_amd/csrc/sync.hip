@@ -642,14 +642,17 @@ hipError_t launch_sync(const uint8_t *mag, uint32_t *lists, int32_t *list_counts
 }
 
 hipError_t launch_heap(const uint32_t *lists, const int32_t *list_counts, ft8gpu_candidate *cands,
-                       int32_t *counts, int nframes, int max_candidates, hipStream_t s, bool latency_hidden) {
+                       int32_t *counts, int nframes, int max_candidates, unsigned debug_flags, hipStream_t s, bool latency_hidden) {
     if (nframes < 1) return hipSuccess;
     // One lane per frame (ft8_heap_simt_kernel) issues a tenth of the instructions but takes about 0.55 ms whatever the
     // number of frames (0.1-0.3 ms for the forms below): the batch pipeline asks for it when the kernels it runs beside
     // are long enough to cover that (latency_hidden), everybody else gets the short chain.
-    // (FT8GPU_HEAP_SIMT=0 never, =2 whenever the cap allows: the parity test of this form)
-    static const int simt = [] { const char *e = getenv("FT8GPU_HEAP_SIMT"); return e ? atoi(e) : 1; }();
-    if (max_candidates <= 128 && ((simt == 1 && latency_hidden && nframes >= 256) || simt == 2)) {
+    // (Test hooks, per context: FT8GPU_DBG_HEAP_LANE_PER_FRAME takes it whenever the cap allows, FT8GPU_DBG_HEAP_WAVE_PER_FRAME never.)
+    const bool lane_form_possible = max_candidates <= 128;
+    const bool want_lane_form = (debug_flags & FT8GPU_DBG_HEAP_LANE_PER_FRAME) ? true
+                              : (debug_flags & FT8GPU_DBG_HEAP_WAVE_PER_FRAME) ? false
+                              : (latency_hidden && nframes >= 256);
+    if (lane_form_possible && want_lane_form) {
         hipLaunchKernelGGL(ft8_heap_simt_kernel, dim3((nframes + 63) / 64), dim3(64), (size_t)max_candidates * 64 * sizeof(uint32_t), s,
                            lists, list_counts, cands, counts, nframes, max_candidates);
         return hipGetLastError();

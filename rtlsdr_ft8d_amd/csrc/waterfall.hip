@@ -3,14 +3,18 @@
 //   rtlsdr_ft8d.c:1413-1433  |X|^2 -> 10*log10 -> (int)(2*dB+240) clamp -> uint8, OSR de-interleave
 //
 // Design (gfx950, wave64):
-//   * workgroups of 4 waves walk lists of work items; an item is (frame, 4 consecutive FFT rows).
-//     The 1792-sample span those rows cover is read with 16-byte coalesced loads and staged in LDS
-//     (each sample feeds up to 4 overlapping rows: hop 256, length 1024); the 768 samples shared
-//     with the next item of the frame come from the XCD's L2 (see xcd_item).
-//   * one wave per FFT row, 16 complex points per lane.  1024 = 16 x 16 x 4: two radix-4 stages in
-//     registers, exchange through a padded (conflict-free) LDS buffer, two more radix-4 stages,
-//     second exchange, last radix-4 stage computing only the outputs that land in bins 0..511.
-//   * window and all twiddle factors live in registers for the lifetime of the wave.
+//   * one wave per FFT row, 16 complex points per lane, four waves (four consecutive rows) per workgroup.  Every wave
+//     reads the 1024 samples of its row straight from global memory (32 coalesced 256-byte loads); the 75 % overlap
+//     of consecutive rows is served by the CU's vector L1, the overlap between workgroups by the XCD's L2 (xcd_item).
+//   * 1024 = 16 x 16 x 4: two radix-4 stages in registers, exchange through a padded (conflict-free) per-wave LDS
+//     buffer, two more radix-4 stages, then the last radix-4 stage, of which only the outputs that land in bins
+//     0..511 are computed.  The inputs of that last stage differ in the LOWEST digit of the point index only, and the
+//     second layout puts that digit into the lane's ROW number (lane >> 4), so the second exchange is a 4 x 4
+//     transpose of registers across the four 16-lane rows of the wave: v_permlane16_swap + v_permlane32_swap (gfx950),
+//     one instruction per register, no LDS.  (Forms with that exchange through LDS, or inside the quads with DPP
+//     selects, are kept behind per-context debug flags: bit-identical, measured in DESIGN.md.)
+//   * stage-0 twiddles live in registers, those of stages 1-3 (multiples of 4) in a 2 KB LDS table, the window is
+//     re-read from L1 per row: 37.9 KB of LDS and at most 128 VGPRs, i.e. four workgroups per CU.
 //   * the dB quantiser is evaluated against a 256-entry threshold table derived on the host from
 //     the reference expression itself (host libm log10f), so the uint8 result is bit-identical to
 //     (int)(2*(10.0f*log10f(1e-12f + mag2*4.0f/(NFFT*NFFT)))+240); v_log_f32 only provides a
@@ -65,36 +69,6 @@ __device__ __forceinline__ void bfly4(c32 &a0, c32 &a1, c32 &a2, c32 &a3) {
     a3 = add_mul_pi(t1, t3);
 }
 
-// two consecutive radix-4 stages on 16 register-resident points, register a = a_lo + 4*q
-__device__ __forceinline__ void pass16(c32 (&x)[16], const float2 (&twA)[4][3], const float2 (&twB)[3]) {
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        bfly4(x[a], x[a + 4], x[a + 8], x[a + 12]);
-        x[a + 4]  = cmul(x[a + 4],  twA[a][0]);
-        x[a + 8]  = cmul(x[a + 8],  twA[a][1]);
-        x[a + 12] = cmul(x[a + 12], twA[a][2]);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        bfly4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
-        x[4 * q + 1] = cmul(x[4 * q + 1], twB[0]);
-        x[4 * q + 2] = cmul(x[4 * q + 2], twB[1]);
-        x[4 * q + 3] = cmul(x[4 * q + 3], twB[2]);
-    }
-}
-
-__device__ __forceinline__ int pad_idx(int p) { return p + 4 * (p >> 6); }
-
-// Layout of the SECOND exchange (between stages 3 and 4).  Stage 4 reads the four inputs 4c .. 4c+3 of
-// butterfly c as two 16-byte units; with the inputs contiguous (32 bytes per lane) every ds_read_b128 hits
-// each bank twice.  So the two halves of a butterfly's inputs live in two regions 260 units apart (unit =
-// two complex values = 16 bytes; 260 = 4 mod 8 staggers the regions by half a bank cycle), and the unit index
-// is XOR-swizzled with bits 4..5 of c:
-//     position of element 4c + e  =  2 * ((c ^ ((c >> 4) & 3)) + 260 * (e >> 1)) + (e & 1)      [complex values]
-// Both sides are then conflict-free: the 16 lanes of a ds_read_b128 group cover 16 distinct units mod 16, and
-// the 16 lanes of a ds_write_b64 group (four values of c >> 4, four of e) cover all 32 banks.
-constexpr int kHalfUnits = 260;
-
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -130,8 +104,6 @@ __device__ __forceinline__ void quantise2(c32 a, c32 b, const float *qthr, unsig
 }
 
 constexpr int kXbuf = 1088;     // 1024 + 4 per 64 padding, complex entries per wave
-constexpr int kVecPerPlane = kWfSpan / 4;                 // float4 per plane of a work item's span
-static_assert(kVecPerPlane > 256 && kVecPerPlane <= 512, "two I and two Q vectors per thread (the second pair for part of the workgroup)");
 
 // XCD-aware work order.  The dispatcher places workgroup w on XCD w % 8 (each XCD has its own L2).
 // Consecutive chunks of a frame share 768 of their samples, so every XCD is given whole frames
@@ -146,34 +118,59 @@ __device__ __forceinline__ int xcd_item(int step, int nframes) {
     return frame < nframes ? frame * kWfItemsPerFrame + chunk : -1;
 }
 
-// address of the i-th float4 of one plane (0 = I, 1 = Q) of a work item's span
-__device__ __forceinline__ const float4 *item_vec(const float *__restrict__ iq, int item, int plane, int i) {
-    const int frame = item / kWfItemsPerFrame;
-    const int chunk = item - frame * kWfItemsPerFrame;
-    const float *base = iq + (size_t)frame * (2 * kNSamples) + chunk * (kWfRowsPerItem * 256);
-    return reinterpret_cast<const float4 *>(base + plane * kNSamples) + i;
+// How the four inputs of a last-stage butterfly reach one lane (template parameter of the kernel):
+//   kStage4Rows  the product.  The second layout keeps the lowest digit of the point index in the lane's ROW number:
+//                lane (j, b) = (lane >> 4, lane & 15) holds point 64 b + j + 4 a in register a, so the inputs 4c .. 4c+3 of
+//                butterfly c = 16 b + a are register a of lanes b, 16 + b, 32 + b, 48 + b -- a 4 x 4 transpose of
+//                registers across the four rows of the wave, which gfx950 does with v_permlane16_swap (odd rows of one
+//                register against even rows of another) and v_permlane32_swap (upper half against lower half): one
+//                instruction per register, 32 per row of the waterfall, no select masks, no LDS.
+//   kStage4Quad  round 3's form: the digit sits in the lane's position inside its quad, the transpose is two rounds of
+//                fused select + quad permute (quad_transpose.h), 64 instructions per row.
+//   kStage4Lds   the exchange through LDS (16 ds_write_b64 + 8 ds_read_b128 per row, XOR-swizzled layout below).
+// All three run the same butterflies in the same order: bit-identical output (test_waterfall_forms_are_bit_identical).
+constexpr int kStage4Rows = 0, kStage4Quad = 1, kStage4Lds = 2;
+
+// first exchange: point p of the row sits at complex slot p + PAD * (p >> 6).  Writes are lane-contiguous whatever PAD is;
+// the reads of the second layout want 4 b + j (quad / LDS forms: PAD 4) or 2 b + j (row form: PAD 2) to run through
+// all 32 eight-byte bank pairs within a 32-lane group.
+template <int PAD> __device__ __forceinline__ int pad_idx(int p) { return p + PAD * (p >> 6); }
+
+// 4 x 4 transpose of four VGPRs across the four 16-lane rows of the wave: afterwards register m of a lane in row r holds
+// what register r held in the lane of row m (same position in the row).  (The compiler's hazard recogniser knows the
+// builtins: it puts the two wait states between a VALU write and the swap that reads it.)
+__device__ __forceinline__ void row_transpose4(float &r0, float &r1, float &r2, float &r3) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(r0), __float_as_uint(r1), false, false);   // row bit 0 against register bit 0
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(r2), __float_as_uint(r3), false, false);
+    const auto c = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);                                   // row bit 1 against register bit 1
+    const auto d = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+    r0 = __uint_as_float(c[0]);
+    r1 = __uint_as_float(d[0]);
+    r2 = __uint_as_float(c[1]);
+    r3 = __uint_as_float(d[1]);
 }
 
-
-// Last radix-4 stage + quantiser + row store, form without the second LDS exchange.  After stages 2 and 3 lane
-// (b, j) = (lane >> 2, lane & 3) holds point 64 b + j + 4 a in register a, and the inputs 4c .. 4c+3 of stage-4 butterfly
-// c = 16 b + a are register a of the four lanes of quad b: a 4 x 4 transpose inside the quad (quad_transpose.h: fused
-// select + quad permute, 64 single-rate VALU instructions per row) hands lane j all four inputs of the butterflies
-// c = 16 b + 4 i + j, i = 0..3 -- no 8 KB round trip through the LDS store path, which is what bounds this kernel.
-// Outputs are in digit-reversed order: butterfly c holds bins rev4(c) and 256 + rev4(c), rev4(c) = (b >> 2) + 4 (b & 3) +
-// 16 i + 64 j.  Same butterflies, same operation order: bit-identical to the exchange form.
-__device__ __forceinline__ void stage4_quad(c32 (&x)[16], int lane, const float *s_thr, unsigned char *ob) {
+// Last radix-4 stage + quantiser + staging of the row's 512 output bytes, for the two forms without the second LDS
+// exchange.  After the transposes lane (b, j) holds all four inputs of the butterflies c = 16 b + 4 i + j, i = 0..3, in
+// registers 4i .. 4i+3.  Outputs are in digit-reversed order: butterfly c holds bins rev4(c) and 256 + rev4(c),
+// rev4(c) = (b >> 2) + 4 (b & 3) + 16 i + 64 j.
+template <int STAGE4>
+__device__ __forceinline__ void stage4_in_registers(c32 (&x)[16], int b, int j, const float *s_thr, unsigned char *ob) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float r0 = x[4 * i].x, r1 = x[4 * i + 1].x, r2 = x[4 * i + 2].x, r3 = x[4 * i + 3].x;
         float m0 = x[4 * i].y, m1 = x[4 * i + 1].y, m2 = x[4 * i + 2].y, m3 = x[4 * i + 3].y;
-        quad_transpose4x2(r0, r1, r2, r3, m0, m1, m2, m3);
+        if (STAGE4 == kStage4Quad) {
+            quad_transpose4x2(r0, r1, r2, r3, m0, m1, m2, m3);
+        } else {
+            row_transpose4(r0, r1, r2, r3);
+            row_transpose4(m0, m1, m2, m3);
+        }
         x[4 * i] = c32{ r0, m0 };
         x[4 * i + 1] = c32{ r1, m1 };
         x[4 * i + 2] = c32{ r2, m2 };
         x[4 * i + 3] = c32{ r3, m3 };
     }
-    const int b = lane >> 2, j = lane & 3;
     const int kbase = (b >> 2) + 4 * (b & 3) + 64 * j;
     unsigned char *o0 = ob + 256 * (kbase & 1) + (kbase >> 1);            // [freq_sub = k & 1][pos = k >> 1], bins kbase + 16 i
 #pragma unroll
@@ -189,165 +186,6 @@ __device__ __forceinline__ void stage4_quad(c32 (&x)[16], int lane, const float 
     }
 }
 
-template <bool QUAD4>
-__global__ __launch_bounds__(256)
-void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ mag,
-                          const Ft8Tables *__restrict__ tab, int nitems, int nframes, int xcd_order) {
-    __shared__ __attribute__((aligned(16))) float2 s_in[kWfSpan];            // staged samples, (I, Q) interleaved
-    __shared__ __attribute__((aligned(16))) float2 s_x[4][kXbuf];            // per-wave exchange
-    __shared__ __attribute__((aligned(16))) float s_thr[260];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: keep it in an SGPR
-
-    for (int i = tid; i < 260; i += 256) s_thr[i] = tab->qthr[i];
-
-    // register-resident constants: window taps and twiddles of this lane
-    float hw[16];
-#pragma unroll
-    for (int a = 0; a < 16; ++a) hw[a] = tab->hann[lane + 64 * a];
-    float2 twA1[4][3], twB1[3], twA2[4][3], twB2[3];
-    const int j2 = lane & 3, b16 = lane >> 2;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int j0 = lane + 64 * a;          // stage 0: L = 1024, T = 1
-        const int jj = j2 + 4 * a;             // stage 2: L = 64,   T = 16
-#pragma unroll
-        for (int q = 1; q < 4; ++q) {
-            twA1[a][q - 1] = tab->tw[(q * j0) & 1023];
-            twA2[a][q - 1] = tab->tw[(q * jj * 16) & 1023];
-        }
-    }
-#pragma unroll
-    for (int q = 1; q < 4; ++q) {
-        twB1[q - 1] = tab->tw[(q * lane * 4) & 1023];     // stage 1: L = 256, T = 4
-        twB2[q - 1] = tab->tw[(q * j2 * 64) & 1023];      // stage 3: L = 16,  T = 64
-    }
-
-    float2 *xb = s_x[wave];
-    // the 512 output bytes of a row are staged at the front of the wave's exchange buffer: by then every lane has
-    // issued its stage-4 reads, and a wave's LDS operations execute in order.  (Keeping the workgroup at 50 KB
-    // leaves room for a heap-replay workgroup of the other half-batch beside three resident workgroups per CU.)
-    unsigned char *ob = reinterpret_cast<unsigned char *>(xb);
-    // second exchange: this lane writes elements 64*b16 + j2 + 4a (c = 16*b16 + a, e = j2) and reads butterflies lane + 64 i
-    int wbase2[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) wbase2[r] = 32 * b16 + 2 * kHalfUnits * (j2 >> 1) + (j2 & 1) + 2 * (r ^ (b16 & 3));
-    const int rbase2 = 2 * (lane ^ ((lane >> 4) & 3));
-
-    // software pipeline over work items: the next item's samples travel HBM -> registers while the
-    // current item's rows are transformed, and are dropped into LDS at the top of the next round.
-    // A thread fetches the same four samples of both planes, so it can store them as (I, Q) pairs:
-    // the row loads below are then single 8-byte reads that land in a register pair as a complex value.
-    float4 pI0, pQ0, pI1, pQ1;
-    pI0 = pQ0 = pI1 = pQ1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool tail = tid + 256 < kVecPerPlane;               // the second pair exists for part of the workgroup only
-#define FT8_PREFETCH(ITEM)                                           \
-    do {                                                             \
-        pI0 = *item_vec(iq, (ITEM), 0, tid);                         \
-        pQ0 = *item_vec(iq, (ITEM), 1, tid);                         \
-        if (tail) {                                                  \
-            pI1 = *item_vec(iq, (ITEM), 0, tid + 256);               \
-            pQ1 = *item_vec(iq, (ITEM), 1, tid + 256);               \
-        }                                                            \
-    } while (0)
-    // item sequence of this workgroup: XCD-aware when the grid is a multiple of 8 workgroups, else strided
-    int step = 0;
-    int item = xcd_order ? xcd_item(0, nframes) : ((int)blockIdx.x < nitems ? (int)blockIdx.x : -1);
-    if (item >= 0) FT8_PREFETCH(item);
-
-    while (item >= 0) {
-        const int frame = item / kWfItemsPerFrame;
-        const int chunk = item - frame * kWfItemsPerFrame;
-
-        __syncthreads();                        // previous item's readers are done with s_in
-        {
-            float4 *dst = reinterpret_cast<float4 *>(s_in);             // float4 = two (I, Q) pairs
-            dst[2 * tid]     = make_float4(pI0.x, pQ0.x, pI0.y, pQ0.y);
-            dst[2 * tid + 1] = make_float4(pI0.z, pQ0.z, pI0.w, pQ0.w);
-            if (tail) {
-                dst[2 * (tid + 256)]     = make_float4(pI1.x, pQ1.x, pI1.y, pQ1.y);
-                dst[2 * (tid + 256) + 1] = make_float4(pI1.z, pQ1.z, pI1.w, pQ1.w);
-            }
-        }
-        __syncthreads();
-        ++step;
-        int next_item;
-        if (xcd_order) next_item = xcd_item(step, nframes);
-        else { next_item = item + (int)gridDim.x; if (next_item >= nitems) next_item = -1; }
-        if (next_item >= 0) FT8_PREFETCH(next_item);
-
-#pragma unroll 1
-        for (int rr = 0; rr < kWfRowsPerItem / 4; ++rr) {
-            const int row_in_item = wave * (kWfRowsPerItem / 4) + rr;
-            const float2 *sIQ = s_in + row_in_item * 256;
-
-            c32 x[16];
-#pragma unroll
-            for (int a = 0; a < 16; ++a) {      // rtlsdr_ft8d.c:1407-1410
-                const float2 v = sIQ[lane + 64 * a];
-                x[a] = c32{ v.x, v.y } * c32{ hw[a], hw[a] };
-            }
-            pass16(x, twA1, twB1);              // stages 0, 1
-#pragma unroll
-            for (int a = 0; a < 16; ++a) xb[pad_idx(lane + 64 * a)] = make_float2(x[a].x, x[a].y);
-            wave_lds_sync();
-#pragma unroll
-            for (int a = 0; a < 16; ++a) {
-                const float2 v = xb[pad_idx(64 * b16 + j2 + 4 * a)];
-                x[a] = c32{ v.x, v.y };
-            }
-            pass16(x, twA2, twB2);              // stages 2, 3
-            if (QUAD4) {
-                wave_lds_sync();                    // every lane has read its stage-2 inputs out of xb: its front becomes the row's output bytes
-                stage4_quad(x, lane, s_thr, ob);
-            } else {
-    #pragma unroll
-                for (int a = 0; a < 16; ++a) xb[wbase2[a & 3] + 8 * (a >> 2)] = make_float2(x[a].x, x[a].y);
-                wave_lds_sync();
-    
-                // stage 4 (L = 4, no twiddles): butterfly c = lane + 64*i holds bins k0+i (y0) and 256+k0+i (y1)
-                unsigned q0[4], q1[4];
-    #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float4 *src = reinterpret_cast<const float4 *>(xb + rbase2 + 128 * i);      // butterfly c = lane + 64 i
-                    const float4 v01 = src[0], v23 = src[kHalfUnits];
-                    const c32 a0 = { v01.x, v01.y }, a1 = { v01.z, v01.w }, a2 = { v23.x, v23.y }, a3 = { v23.z, v23.w };
-                    const c32 t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = a1 - a3;
-                    const c32 y0 = t0 + t2;
-                    const c32 y1 = add_mul_mi(t1, t3);
-                    quantise2(y0, y1, s_thr, q0[i], q1[i]);
-                }
-                // ob aliases the front of xb (float4 loads above, 16-bit stores below, different types): make the order
-                // "every lane's stage-4 loads, then the stores" explicit instead of leaving it to the schedule
-                wave_lds_sync();
-                // bins k0..k0+3 -> [freq_sub = k&1][pos = k>>1]  (rtlsdr_ft8d.c:1420-1428)
-                const int k0 = 64 * (lane & 3) + 16 * ((lane >> 2) & 3) + 4 * (lane >> 4);
-                const int h = k0 >> 1;
-                *reinterpret_cast<unsigned short *>(ob + h)             = (unsigned short)(q0[0] | (q0[2] << 8));
-                *reinterpret_cast<unsigned short *>(ob + 256 + h)       = (unsigned short)(q0[1] | (q0[3] << 8));
-                *reinterpret_cast<unsigned short *>(ob + 128 + h)       = (unsigned short)(q1[0] | (q1[2] << 8));
-                *reinterpret_cast<unsigned short *>(ob + 256 + 128 + h) = (unsigned short)(q1[1] | (q1[3] << 8));
-            }
-            wave_lds_sync();
-            const int row = chunk * kWfRowsPerItem + row_in_item;       // = 2*idx_block + time_sub
-            uint2 *dst = reinterpret_cast<uint2 *>(mag + (size_t)frame * kMagArray + (size_t)row * 512);
-            dst[lane] = reinterpret_cast<const uint2 *>(ob)[lane];
-            wave_lds_sync();                    // ob / xb are rewritten by the next row
-        }
-        item = next_item;
-    }
-}
-
-
-// ---- second form of the kernel: four workgroups per CU ----------------------------------------------------------------
-// The form above stages a work item's 1792 samples in LDS (14 KB beside 35 KB of exchange buffers: three workgroups per
-// CU) and keeps 76 per-lane constants in registers (160 VGPRs: three waves per SIMD).  Here every wave reads the 1024
-// samples of its row straight from global memory -- 32 coalesced 256-byte loads; the four waves of a workgroup take
-// four consecutive rows, whose 75 % overlap is served by the CU's vector L1 -- so there is no staging buffer, no
-// __syncthreads() and no prefetch registers, and the twiddles of stages 1-3 (multiples of 4: a 256-entry table, 2 KB
-// of LDS) are fetched where they are used instead of living in 36 VGPRs.  38 KB of LDS and at most 128 VGPRs:
-// four workgroups per CU, four waves per SIMD.  Same butterflies in the same order: bit-identical output.
 __device__ __forceinline__ void bfly_stage_a(c32 (&x)[16], int a, float2 w1, float2 w2, float2 w3) {
     bfly4(x[a], x[a + 4], x[a + 8], x[a + 12]);
     x[a + 4]  = cmul(x[a + 4],  w1);
@@ -361,10 +199,13 @@ __device__ __forceinline__ void bfly_stage_b(c32 (&x)[16], int q, float2 w1, flo
     x[4 * q + 3] = cmul(x[4 * q + 3], w3);
 }
 
-template <bool QUAD4>
+// (Round 3 also had a form that staged a work item's 1792 samples in LDS and kept window and twiddles in 76 registers:
+// three workgroups per CU, 0.885 ms against 0.891 ms per 4096 frames for this one in interleaved runs -- equal, and it
+// left no room for the heap replay beside it; removed in round 4, profiles/r03_waterfall_forms.json has its counters.)
+template <int STAGE4>
 __global__ __launch_bounds__(256, 4)
-void ft8_waterfall_kernel_v2(const float *__restrict__ iq, uint8_t *__restrict__ mag,
-                             const Ft8Tables *__restrict__ tab, int nitems, int nframes, int xcd_order) {
+void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ mag,
+                          const Ft8Tables *__restrict__ tab, int nitems, int nframes, int xcd_order) {
     __shared__ __attribute__((aligned(16))) float2 s_x[4][kXbuf];            // per-wave exchange
     __shared__ __attribute__((aligned(16))) float2 s_tw4[256];               // tw[4 k]
     __shared__ __attribute__((aligned(16))) float s_thr[260];
@@ -375,7 +216,10 @@ void ft8_waterfall_kernel_v2(const float *__restrict__ iq, uint8_t *__restrict__
     s_tw4[tid] = tab->tw[4 * tid];
 
     float2 twA1[4][3];                                                       // stage 0: L = 1024, every index occurs
-    const int j2 = lane & 3, b16 = lane >> 2;
+    // second layout: lane (b16, j2) holds point 64 b16 + j2 + 4 a in register a
+    constexpr bool kRows = STAGE4 == kStage4Rows;
+    constexpr int kPad = kRows ? 2 : 4;
+    const int j2 = kRows ? lane >> 4 : lane & 3, b16 = kRows ? lane & 15 : lane >> 2;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -383,7 +227,17 @@ void ft8_waterfall_kernel_v2(const float *__restrict__ iq, uint8_t *__restrict__
     __syncthreads();                                                         // tables are in place (the only barrier)
 
     float2 *xb = s_x[wave];
+    // the 512 output bytes of a row are staged at the front of the wave's exchange buffer (a wave's LDS operations
+    // execute in order, and every lane has read its inputs out of the buffer by then)
     unsigned char *ob = reinterpret_cast<unsigned char *>(xb);
+    // Layout of the SECOND exchange of the LDS form (between stages 3 and 4).  Stage 4 reads the four inputs 4c .. 4c+3 of
+    // butterfly c as two 16-byte units; with the inputs contiguous (32 bytes per lane) every ds_read_b128 hits each
+    // bank twice.  So the two halves of a butterfly's inputs live in two regions 260 units apart (unit = two complex
+    // values = 16 bytes; 260 = 4 mod 8 staggers the regions by half a bank cycle), and the unit index is XOR-swizzled
+    // with bits 4..5 of c:  position of element 4c + e = 2 * ((c ^ ((c >> 4) & 3)) + 260 * (e >> 1)) + (e & 1).
+    // Both sides are then conflict-free: the 16 lanes of a ds_read_b128 group cover 16 distinct units mod 16, and the
+    // 16 lanes of a ds_write_b64 group (four values of c >> 4, four of e) cover all 32 banks.
+    constexpr int kHalfUnits = 260;
     int wbase2[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) wbase2[r] = 32 * b16 + 2 * kHalfUnits * (j2 >> 1) + (j2 & 1) + 2 * (r ^ (b16 & 3));
@@ -416,11 +270,11 @@ void ft8_waterfall_kernel_v2(const float *__restrict__ iq, uint8_t *__restrict__
             for (int q = 0; q < 4; ++q) bfly_stage_b(x, q, w1, w2, w3);
         }
 #pragma unroll
-        for (int a = 0; a < 16; ++a) xb[pad_idx(lane + 64 * a)] = make_float2(x[a].x, x[a].y);
+        for (int a = 0; a < 16; ++a) xb[pad_idx<kPad>(lane + 64 * a)] = make_float2(x[a].x, x[a].y);
         wave_lds_sync();
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
-            const float2 v = xb[pad_idx(64 * b16 + j2 + 4 * a)];
+            const float2 v = xb[pad_idx<kPad>(64 * b16 + j2 + 4 * a)];
             x[a] = c32{ v.x, v.y };
         }
         // stages 2, 3
@@ -434,16 +288,17 @@ void ft8_waterfall_kernel_v2(const float *__restrict__ iq, uint8_t *__restrict__
 #pragma unroll
             for (int q = 0; q < 4; ++q) bfly_stage_b(x, q, w1, w2, w3);
         }
-        if (QUAD4) {
-            wave_lds_sync();
-            stage4_quad(x, lane, s_thr, ob);
+        if (STAGE4 != kStage4Lds) {
+            wave_lds_sync();                            // every lane has read its stage-2 inputs out of xb: its front becomes the row's output bytes
+            stage4_in_registers<STAGE4>(x, b16, j2, s_thr, ob);
         } else {
-    #pragma unroll
+#pragma unroll
             for (int a = 0; a < 16; ++a) xb[wbase2[a & 3] + 8 * (a >> 2)] = make_float2(x[a].x, x[a].y);
             wave_lds_sync();
-    
+
+            // stage 4 (L = 4, no twiddles): butterfly c = lane + 64*i holds bins k0+i (y0) and 256+k0+i (y1)
             unsigned q0[4], q1[4];
-    #pragma unroll
+#pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float4 *src = reinterpret_cast<const float4 *>(xb + rbase2 + 128 * i);
                 const float4 v01 = src[0], v23 = src[kHalfUnits];
@@ -454,6 +309,7 @@ void ft8_waterfall_kernel_v2(const float *__restrict__ iq, uint8_t *__restrict__
                 quantise2(y0, y1, s_thr, q0[i], q1[i]);
             }
             wave_lds_sync();                            // every lane's stage-4 loads before the stores into the same bytes
+            // bins k0..k0+3 -> [freq_sub = k&1][pos = k>>1]  (rtlsdr_ft8d.c:1420-1428)
             const int k0 = 64 * (lane & 3) + 16 * ((lane >> 2) & 3) + 4 * (lane >> 4);
             const int h = k0 >> 1;
             *reinterpret_cast<unsigned short *>(ob + h)             = (unsigned short)(q0[0] | (q0[2] << 8));
@@ -464,7 +320,7 @@ void ft8_waterfall_kernel_v2(const float *__restrict__ iq, uint8_t *__restrict__
         wave_lds_sync();
         uint2 *dst = reinterpret_cast<uint2 *>(mag + (size_t)frame * kMagArray + (size_t)row * 512);
         dst[lane] = reinterpret_cast<const uint2 *>(ob)[lane];
-        wave_lds_sync();
+        wave_lds_sync();                                // ob / xb are rewritten by the next row
 
         ++step;
         if (xcd_order) item = xcd_item(step, nframes);
@@ -474,27 +330,20 @@ void ft8_waterfall_kernel_v2(const float *__restrict__ iq, uint8_t *__restrict__
 
 }  // namespace
 
+// stage4: 0 = the product (row transposes), FT8GPU_DBG_WATERFALL_QUAD / FT8GPU_DBG_WATERFALL_LDS select the other forms
 hipError_t launch_waterfall(const float *iq, uint8_t *mag, const Ft8Tables *tab, int nframes,
-                            int num_cus, hipStream_t s) {
+                            int num_cus, unsigned debug_flags, hipStream_t s) {
     const int nitems = nframes * kWfItemsPerFrame;
-    int grid = num_cus * kWfGridPerCu;           // workgroups per CU (LDS-limited), persistent
+    int grid = num_cus * 16;                     // four resident workgroups per CU (LDS- and VGPR-limited), four rounds of them
     if (grid > nitems) grid = nitems;
     if (grid < 1) return hipSuccess;
     // XCD-aware order needs whole groups of 8 workgroups and enough frames to give every XCD work
-    const int xcd_order = (grid % 8 == 0 && nframes >= 64) ? 1 : 0;
-    // form 2 (four workgroups per CU, no staging buffer) is the product; FT8GPU_WATERFALL_FORM=1 selects the staged form
-    static const int form = [] { const char *e = getenv("FT8GPU_WATERFALL_FORM"); return e ? atoi(e) : 2; }();
-    // last stage: second exchange through LDS (default) or "quad": 4 x 4 transposes inside the quads, no second exchange
-    static const bool quad4 = [] { const char *e = getenv("FT8GPU_WATERFALL_STAGE4"); return e && e[0] == 'q'; }();
-    if (form == 2) {
-        int grid2 = num_cus * 16;                  // four resident workgroups per CU, four rounds of them
-        if (grid2 > nitems) grid2 = nitems;
-        const int xo = (grid2 % 8 == 0 && nframes >= 64) ? 1 : 0;
-        if (quad4) hipLaunchKernelGGL(ft8_waterfall_kernel_v2<true>, dim3(grid2), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xo);
-        else hipLaunchKernelGGL(ft8_waterfall_kernel_v2<false>, dim3(grid2), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xo);
-        return hipGetLastError();
-    }
-    if (quad4) hipLaunchKernelGGL(ft8_waterfall_kernel<true>, dim3(grid), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xcd_order);
-    else hipLaunchKernelGGL(ft8_waterfall_kernel<false>, dim3(grid), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xcd_order);
+    const int xo = (grid % 8 == 0 && nframes >= 64) ? 1 : 0;
+    if (debug_flags & FT8GPU_DBG_WATERFALL_LDS)
+        hipLaunchKernelGGL(ft8_waterfall_kernel<kStage4Lds>, dim3(grid), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xo);
+    else if (debug_flags & FT8GPU_DBG_WATERFALL_QUAD)
+        hipLaunchKernelGGL(ft8_waterfall_kernel<kStage4Quad>, dim3(grid), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xo);
+    else
+        hipLaunchKernelGGL(ft8_waterfall_kernel<kStage4Rows>, dim3(grid), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xo);
     return hipGetLastError();
 }

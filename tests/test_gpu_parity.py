@@ -501,7 +501,7 @@ def test_bp_division_chains_by_exhaustion():
     assert 1.0 < r["tanh_max"] < 1.0075 and r["tanh_max"] ** 6 < 1.05, r          # 1.05 = bpm::kAtanhMaxAbs
     with ft8.Decoder(device=0, max_frames=1) as d:
         with pytest.raises(ft8.Ft8GpuError, match="unknown bits"):
-            d.set_debug_flags(8)
+            d.set_debug_flags(128)
 
 
 def test_decode_pipeline_form_of_the_kernel(oracle):
@@ -748,34 +748,32 @@ def test_decode_randomised_waterfall_sweep(oracle, gpu_decoder):
     assert total == 3840
 
 
-@pytest.mark.parametrize("form,stage4", [("1", "lds"), ("2", "quad"), ("1", "quad")])
-def test_waterfall_other_forms_are_bit_identical(oracle, tmp_path, form, stage4):
-    """the staged form of the waterfall kernel (FT8GPU_WATERFALL_FORM=1: 4-row items in LDS, three workgroups per CU; the
-    product is form 2: direct global loads, four workgroups per CU) and the last stage without the second LDS exchange (FT8GPU_WATERFALL_STAGE4=quad: 4 x 4 transposes inside the quads with fused select +
-    quad permute) must produce the same bytes as the oracle; the form is chosen once per process, so a child process runs it"""
-    import subprocess
-    import sys
-    code = r'''
-import os, sys, numpy as np
-sys.path.insert(0, os.path.join(os.environ["FT8_ROOT"], "tests")); sys.path.insert(0, os.environ["FT8_ROOT"])
-import oracle_lib, synth_util as S, rtlsdr_ft8d_amd as ft8
-oracle_lib.lib()
-enc = S.oracle_encode_fn(oracle_lib)
-frames = [np.stack(oracle_lib.selftest_signal())] + [S.make_frame(s, n, enc)[0] for s, n in ((3, 5), (4, 30), (5, 0))]
-frames.append(np.zeros((2, 48000), np.float32))
-rng = np.random.default_rng(2); big = rng.normal(0, 0.2, (300, 2, 48000)).astype(np.float32)     # enough frames for the XCD-aware order
-iq = np.concatenate([np.stack(frames), big])
-with ft8.Decoder(device=0, max_frames=iq.shape[0]) as d:
-    mag = d.waterfall(iq)
-    dec, n = d.decode_batch(iq[:5])
-bad = [k for k in list(range(5)) + [5, 100, 304] if not np.array_equal(mag[k], oracle_lib.waterfall(iq[k, 0], iq[k, 1]))]
-ref = [oracle_lib.subsystem(iq[k, 0], iq[k, 1]) for k in range(5)]
-ok = all(n[k] == ref[k][1] and dec[k].tobytes() == ref[k][0].tobytes() for k in range(5))
-print("RESULT", bad, ok)
-'''
-    env = dict(os.environ, FT8GPU_WATERFALL_FORM=form, FT8GPU_WATERFALL_STAGE4=stage4, FT8_ROOT=ROOT)
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert "RESULT [] True" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+@pytest.mark.parametrize("form", ["rows", "quad", "lds"])
+def test_waterfall_forms_are_bit_identical(oracle, form):
+    """The three forms of the last FFT stage -- 4 x 4 register transposes across the wave's rows with v_permlane16/32_swap
+    (the product), inside the quads with fused select + quad permute (FT8GPU_DBG_WATERFALL_QUAD), and the exchange through
+    LDS (FT8GPU_DBG_WATERFALL_LDS) -- must all produce the oracle's bytes.  The form is a per-context flag, so one
+    process runs all of them (round 3 needed a child process per form: the switch was an environment variable)."""
+    import rtlsdr_ft8d_amd as ft8
+    import synth_util as S
+    enc = S.oracle_encode_fn(oracle)
+    fr = [np.stack(oracle.selftest_signal())] + [S.make_frame(s, n, enc)[0] for s, n in ((3, 5), (4, 30), (5, 0))]
+    fr.append(np.zeros((2, 48000), np.float32))
+    rng = np.random.default_rng(2)
+    big = rng.normal(0, 0.2, (300, 2, 48000)).astype(np.float32)      # enough frames for the XCD-aware work order
+    iq = np.concatenate([np.stack(fr), big])
+    flags = {"rows": 0, "quad": ft8.DBG_WATERFALL_QUAD, "lds": ft8.DBG_WATERFALL_LDS}[form]
+    with ft8.Decoder(device=0, max_frames=iq.shape[0]) as d:
+        d.set_debug_flags(flags)
+        mag = d.waterfall(iq)
+        dec, n = d.decode_batch(iq[:5])
+        with pytest.raises(ft8.Ft8GpuError, match="exclude each other"):
+            d.set_debug_flags(ft8.DBG_WATERFALL_QUAD | ft8.DBG_WATERFALL_LDS)
+    for k in list(range(5)) + [5, 100, 304]:
+        assert np.array_equal(mag[k], oracle.waterfall(iq[k, 0], iq[k, 1])), (form, k)
+    for k in range(5):
+        rdec, rn = oracle.subsystem(iq[k, 0], iq[k, 1])
+        assert n[k] == rn and dec[k].tobytes() == rdec.tobytes(), (form, k)
 
 
 def test_gpu_against_the_independent_numpy_restatement(gpu_decoder, frames, oracle_mags):
@@ -802,34 +800,29 @@ def test_gpu_against_the_independent_numpy_restatement(gpu_decoder, frames, orac
     assert checked > 40
 
 
-def test_heap_one_lane_per_frame_form_is_exact(oracle):
-    """ft8_heap_simt_kernel (one lane per frame; the batch pipeline uses it from 3072 frames on) must return the
-    reference's candidate lists -- order included -- like the wave-per-frame forms: forced for every launch in a child
-    process (FT8GPU_HEAP_SIMT=2) and compared with the oracle at several caps, thresholds and ragged frame counts"""
-    import subprocess
-    import sys
-    code = r'''
-import os, sys, numpy as np
-sys.path.insert(0, os.path.join(os.environ["FT8_ROOT"], "tests")); sys.path.insert(0, os.environ["FT8_ROOT"])
-import oracle_lib, synth_util as S, rtlsdr_ft8d_amd as ft8
-oracle_lib.lib()
-enc = S.oracle_encode_fn(oracle_lib)
-frames = [np.stack(oracle_lib.selftest_signal())] + [S.make_frame(s, n, enc, snr_range=(-20, 0))[0] for s, n in ((3, 5), (4, 30), (5, 60), (6, 0), (7, 45))]
-frames.append(np.zeros((2, 48000), np.float32))
-rng = np.random.default_rng(9)
-mags = [oracle_lib.waterfall(f[0], f[1]) for f in frames] + [rng.integers(0, 256, 94208, dtype=np.uint8) for _ in range(70)]   # 77 frames: two waves, ragged
-mag = np.stack(mags)
-bad = []
-with ft8.Decoder(device=0, max_frames=len(mags)) as d:
-    for cap, ms in ((120, 10), (128, 10), (7, 10), (1, 10), (33, 0), (120, -5), (64, 30)):
-        d.set_params(min_score=ms, max_candidates=cap)
-        cands, counts = d.find_sync(mag)
-        for k in range(len(mags)):
-            ref = oracle_lib.find_sync(mags[k], cap, ms)
-            if counts[k] != len(ref) or not np.array_equal(cands[k, :counts[k]], ref) or cands[k, counts[k]:].tobytes().strip(b"\0"):
-                bad.append((cap, ms, k))
-print("RESULT", bad[:5], len(bad))
-'''
-    env = dict(os.environ, FT8GPU_HEAP_SIMT="2", FT8_ROOT=ROOT)
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
-    assert "RESULT [] 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+@pytest.mark.parametrize("form", ["lane", "wave"])
+def test_heap_forms_are_exact(oracle, form):
+    """ft8_heap_simt_kernel (one lane per frame; the batch pipeline uses it from 3072 frames on) and the wave-per-frame
+    kernel must both return the reference's candidate lists -- order included: each is forced for every launch with its
+    per-context flag and compared with the oracle at several caps, thresholds and ragged frame counts"""
+    import rtlsdr_ft8d_amd as ft8
+    import synth_util as S
+    enc = S.oracle_encode_fn(oracle)
+    fr = [np.stack(oracle.selftest_signal())] + [S.make_frame(s, n, enc, snr_range=(-20, 0))[0] for s, n in ((3, 5), (4, 30), (5, 60), (6, 0), (7, 45))]
+    fr.append(np.zeros((2, 48000), np.float32))
+    rng = np.random.default_rng(9)
+    mags = [oracle.waterfall(f[0], f[1]) for f in fr] + [rng.integers(0, 256, 94208, dtype=np.uint8) for _ in range(70)]   # 77 frames: two waves, ragged
+    mag = np.stack(mags)
+    bad = []
+    with ft8.Decoder(device=0, max_frames=len(mags)) as d:
+        d.set_debug_flags(ft8.DBG_HEAP_LANE_PER_FRAME if form == "lane" else ft8.DBG_HEAP_WAVE_PER_FRAME)
+        for cap, ms in ((120, 10), (128, 10), (7, 10), (1, 10), (33, 0), (120, -5), (64, 30)):
+            d.set_params(min_score=ms, max_candidates=cap)
+            cands, counts = d.find_sync(mag)
+            for k in range(len(mags)):
+                ref = oracle.find_sync(mags[k], cap, ms)
+                if counts[k] != len(ref) or not np.array_equal(cands[k, :counts[k]], ref) or cands[k, counts[k]:].tobytes().strip(b"\0"):
+                    bad.append((cap, ms, k))
+        with pytest.raises(ft8.Ft8GpuError, match="exclude each other"):
+            d.set_debug_flags(ft8.DBG_HEAP_LANE_PER_FRAME | ft8.DBG_HEAP_WAVE_PER_FRAME)
+    assert not bad, bad[:5]
