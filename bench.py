@@ -92,6 +92,9 @@ def parse_args(argv=None):
                          "reach its sustained clock (per-step times from cold: 5.65, 4.82, 4.67, 4.54, 4.48, 4.38, 4.25, 4.25 ... ms, "
                          "tools/perstep_probe.py), which short --warmup values would put inside the timed region; reported in the line")
     ap.add_argument("--no-clock-sampler", action="store_true", help="do not poll the GPU's sysfs clock / power files during the timed region")
+    ap.add_argument("--ctx-last", action="store_true",
+                    help="create the decoder context AFTER the process group and a handful of framework streams (round 3 lost 0.27 ms per step "
+                         "that way: streams shared hardware queues; the context now measures co-execution and re-rolls its side streams)")
     ap.add_argument("--debug-flags", type=int, default=0,
                     help="FT8GPU_DBG_* bits for the decoder context (profiling of the non-product kernel forms; reported in the line, 0 = product)")
     ap.add_argument("--shards", type=int, default=8, help="configs[3] on one GPU: number of contexts / shards")
@@ -299,12 +302,19 @@ def main():
     # streams on three different queues.  (Created after RCCL's and torch's streams, the main and one side stream landed
     # on the same queue and the heap replay of part A no longer ran beside the waterfall of part B: +0.27 ms per step,
     # tools/trace_gaps.py on a rocprofv3 kernel trace.)
-    dec = None
-    if not (args.config == 3 and world == 1):
-        dec = ft8.Decoder(device=local_rank, max_frames=B, min_score=10, max_candidates=maxc, ldpc_iters=20)
+    def make_decoder():
+        d = ft8.Decoder(device=local_rank, max_frames=B, min_score=10, max_candidates=maxc, ldpc_iters=20)
         if args.debug_flags:
-            dec.set_debug_flags(args.debug_flags)
+            d.set_debug_flags(args.debug_flags)
             out["debug_flags"] = args.debug_flags           # not the product configuration
+        # the context has measured whether its streams co-run (ft8gpu_overlap_active): the two-part pipeline or the plain one
+        out["overlap"] = d.overlap_active()
+        return d
+
+    dec = None
+    single_ctx = not (args.config == 3 and world == 1)
+    if single_ctx and not args.ctx_last:
+        dec = make_decoder()
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -312,6 +322,14 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         out["rccl_ranks"] = dist.get_world_size()          # what RCCL itself was initialised with
         out["backend"] = dist.get_backend()
+    if single_ctx and args.ctx_last:
+        held = [torch.cuda.Stream(device=dev) for _ in range(6)]       # what a framework would have created by now
+        for st in held:
+            with torch.cuda.stream(st):
+                torch.zeros(1, device=dev)
+        torch.cuda.synchronize()
+        dec = make_decoder()
+        out["ctx_created_last"] = True
 
     if args.config == 3 and world == 1:
         run_config3_one_gpu(args, out, B, nsig, snr, maxc, dev)
@@ -665,14 +683,19 @@ def host_legs(dec, iq, spots, nres, B):
     import torch
     out = {}
     m = min(B, 2048)
-    h = iq[:m].cpu().pin_memory().numpy()
+    import rtlsdr_ft8d_amd as ft8
+    pinned = ft8.PinnedArray((m, 2, ft8.NSAMPLES), np.float32)           # ft8gpu_host_alloc: what a C caller of the host entries would use
+    h = pinned.array
+    h[...] = iq[:m].cpu().numpy()
     dec.decode_batch(h[:min(m, 512)])                                    # warm-up (staging allocation)
     t0 = time.perf_counter()
     d, n = dec.decode_batch(h)
     dt = time.perf_counter() - t0
     same = bool(np.array_equal(n, nres[:m].cpu().numpy())) and d.tobytes() == spots[:m].cpu().numpy().tobytes()
     out["host_fed_frames_per_s"] = round(m / dt, 1)
-    out["host_fed"] = {"frames": m, "ms": round(1e3 * dt, 2), "upload_GBps": round(m * 384000 / dt / 1e9, 1), "records_identical_to_hbm_resident_run": same}
+    out["host_fed"] = {"frames": m, "ms": round(1e3 * dt, 2), "upload_GBps": round(m * 384000 / dt / 1e9, 1), "records_identical_to_hbm_resident_run": same,
+                       "host_memory": "ft8gpu_host_alloc (page-locked)"}
+    pinned.close()
     ncap, npairs = 4, 36_000_000                                         # 15 s at 2.4 Msps
     raw = torch.randint(0, 256, (ncap, 2 * npairs), dtype=torch.uint8, generator=torch.Generator().manual_seed(3)).pin_memory().numpy()
     dec.rx_decimate(raw)                                                 # warm-up at full size (staging buffers are grown on first use)
@@ -686,7 +709,6 @@ def host_legs(dec, iq, spots, nres, B):
     # host pointers in and out, process-global single-frame context (the median of 50 calls; the first call creates it)
     one = iq[0].cpu().numpy()
     i_s, q_s = np.ascontiguousarray(one[0]), np.ascontiguousarray(one[1])
-    import rtlsdr_ft8d_amd as ft8
     ft8.ft8_subsystem(i_s, q_s)
     lat = []
     for _ in range(50):

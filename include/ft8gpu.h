@@ -126,19 +126,25 @@ int  ft8gpu_set_stream(ft8gpu_ctx *ctx, void *hip_stream);
  * throughput kernels relies on (measured: the same pipeline takes 1.48 ms on a borrowed framework stream against 1.28 ms
  * on the context's own at 1024 frames, cap 480). */
 void *ft8gpu_get_stream(ft8gpu_ctx *ctx);
+/* 1: batches of >= 512 frames run the two-part pipeline with the serial kernels (heap replay, spot collection) on side
+ * streams under the throughput kernels of the other part; 0: plain pipeline, one launch per stage (ft8gpu_last_error()
+ * then says why).  Whether streams run side by side depends on which hardware queues HIP hands out, so the context
+ * measures it at ft8gpu_create and again at ft8gpu_set_stream (a 2 ms co-execution probe per pair of streams), replaces
+ * side streams that share a queue with another one, and only falls back when that does not help.  Records are identical
+ * either way. */
+int  ft8gpu_overlap_active(ft8gpu_ctx *ctx);
 /* test hooks, per context (any combination; 0 = product behaviour) */
 #define FT8GPU_DBG_FORCE_IEEE_DIV 1u  /* LDPC kernel: the compiler's IEEE division everywhere (the guard's fallback path) */
 #define FT8GPU_DBG_PIPELINE_FORM  2u  /* ft8gpu_decode_candidates runs the form of the LDPC kernel ft8gpu_decode_batch
                                          uses (no exact error count: ldpc_errors is 0 or 83) */
 #define FT8GPU_DBG_NO_OVERLAP     4u  /* one launch per stage for the whole batch: no two-half overlap, no chunked upload */
 /* alternative, bit-identical forms of kernels (the product form is the one with no bit set; DESIGN.md section 4 has
- * the measurements that picked it).  QUAD and LDS exclude each other, as do the two heap bits. */
-#define FT8GPU_DBG_WATERFALL_QUAD 8u  /* last FFT stage: 4 x 4 transposes inside the quads (DPP selects) instead of across rows */
-#define FT8GPU_DBG_WATERFALL_LDS  16u /* last FFT stage: second exchange through LDS */
-#define FT8GPU_DBG_HEAP_LANE_PER_FRAME 32u  /* heap replay: one lane per frame for every launch the cap allows (<= 128) */
-#define FT8GPU_DBG_HEAP_WAVE_PER_FRAME 64u  /* heap replay: one wave per frame for every launch */
-#define FT8GPU_DBG_ALL            127u
-int  ft8gpu_set_debug_flags(ft8gpu_ctx *ctx, unsigned flags);   /* unknown bits are refused */
+ * the measurements that picked it).  The two heap bits exclude each other. */
+#define FT8GPU_DBG_WATERFALL_LDS  8u  /* last FFT stage: second exchange through LDS instead of register transposes across the wave's rows */
+#define FT8GPU_DBG_HEAP_LANE_PER_FRAME 16u  /* heap replay: one lane per frame for every launch the cap allows (<= 128) */
+#define FT8GPU_DBG_HEAP_WAVE_PER_FRAME 32u  /* heap replay: one wave per frame for every launch */
+#define FT8GPU_DBG_ALL            63u
+int  ft8gpu_set_debug_flags(ft8gpu_ctx *ctx, unsigned flags);   /* unknown bits and excluded pairs are refused */
 /* Proof by exhaustion behind the LDPC kernel's short division chains (csrc/bp_math.h): fast_tanh / fast_atanh of
  * ft8_lib ldpc.c (reached through ft8_decode, rtlsdr_ft8d.c:1476) are functions of one float, so all 2^32 inputs are
  * evaluated on the GPU, fast form against the compiler's IEEE-754 division, on the domain the kernel's guard
@@ -170,7 +176,8 @@ int ft8gpu_decode_batch(ft8gpu_ctx *ctx, const float *iq, int nframes,
  * shard's records land directly at their frame offsets in the caller's HOST arrays -- the gather of the
  * 1 404 B/frame spot records is that placement; no collective is needed when the list is consumed on
  * the host, as the daemon does.  iq / decodes / n_results are host memory (FT8GPU_HOST_PTRS layout of
- * ft8gpu_decode_batch).  Returns 0, or -1 with ft8gpu_last_error() naming the failing shard. */
+ * ft8gpu_decode_batch; take them from ft8gpu_host_alloc when throughput matters: uploads from pageable memory are
+ * staged and do not overlap the kernels).  Returns 0, or -1 with ft8gpu_last_error() naming the failing shard. */
 int ft8gpu_decode_batch_multi(ft8gpu_ctx *const *ctxs, int ndev, const float *iq, int nframes,
                               struct decoder_results *decodes, int32_t *n_results);
 /* Device-resident form: shard g's frames already sit in HBM of ctxs[g]'s GPU (iq_dev[g]: [nframes_dev[g]][2][48000],
@@ -285,6 +292,14 @@ void *ft8gpu_dev_alloc(ft8gpu_ctx *ctx, size_t bytes);
 void  ft8gpu_dev_free(ft8gpu_ctx *ctx, void *p);
 int   ft8gpu_memcpy_h2d(ft8gpu_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int   ft8gpu_memcpy_d2h(ft8gpu_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+/* Page-locked host memory (hipHostMalloc / hipHostFree) for the buffers handed to the FT8GPU_HOST_PTRS entries:
+ * ft8gpu_decode_batch uploads in 512-frame chunks with asynchronous copies under the kernels of the previous chunk,
+ * and ft8gpu_decode_batch_multi does the same on every GPU at once -- which only overlaps (and only reaches the
+ * link rate, about 50 GB/s per GPU) from pinned memory; from malloc'ed memory every copy is staged and serialises with
+ * the kernels.  The reference's own buffers are plain static arrays (rtlsdr_ft8d.c:274-278): a daemon decoding one frame
+ * per 15 s does not need this, a replay that feeds thousands of frames does.  NULL + ft8gpu_last_error() on failure. */
+void *ft8gpu_host_alloc(size_t bytes);
+void  ft8gpu_host_free(void *p);
 
 /* ---- drop-in symbols of the reference (rtlsdr_ft8d.h:155-156, :164) --------------------------
  * Link rtlsdr_ft8d.c against libft8gpu.so instead of its own ft8_subsystem/initFFTW/freeFFTW

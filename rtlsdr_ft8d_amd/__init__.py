@@ -50,7 +50,7 @@ class ReportInfo(C.Structure):
 DATAGRAM_STRIDE = 1408
 STREAM_LEGACY = 1                       # FT8GPU_STREAM_LEGACY (= hipStreamLegacy): the legacy null stream, explicitly
 DBG_FORCE_IEEE_DIV, DBG_PIPELINE_FORM, DBG_NO_OVERLAP = 1, 2, 4      # FT8GPU_DBG_* test hooks (per context)
-DBG_WATERFALL_QUAD, DBG_WATERFALL_LDS, DBG_HEAP_LANE_PER_FRAME, DBG_HEAP_WAVE_PER_FRAME = 8, 16, 32, 64   # other kernel forms
+DBG_WATERFALL_LDS, DBG_HEAP_LANE_PER_FRAME, DBG_HEAP_WAVE_PER_FRAME = 8, 16, 32   # other (bit-identical) kernel forms
 
 
 class Ft8GpuError(RuntimeError):
@@ -63,7 +63,8 @@ ABI_SYMBOLS = [
     "ft8gpu_decode_batch", "ft8gpu_waterfall", "ft8gpu_find_sync", "ft8gpu_score_map",
     "ft8gpu_decode_candidates", "ft8gpu_collect_spots", "ft8gpu_pack77_std", "ft8gpu_encode",
     "ft8gpu_synth_frames", "ft8gpu_synth_frames_at", "ft8gpu_rx_decimate", "ft8gpu_pskreporter_datagrams", "ft8gpu_format_spots",
-    "ft8gpu_dev_alloc", "ft8gpu_dev_free", "ft8gpu_memcpy_h2d", "ft8gpu_memcpy_d2h",
+    "ft8gpu_dev_alloc", "ft8gpu_dev_free", "ft8gpu_memcpy_h2d", "ft8gpu_memcpy_d2h", "ft8gpu_host_alloc", "ft8gpu_host_free",
+    "ft8gpu_overlap_active",
     "ft8gpu_set_debug_flags", "ft8gpu_selftest_bp_math", "ft8gpu_gather_spots", "ft8gpu_gather_shutdown",
     "ft8gpu_shard_workers", "ft8gpu_decode_batch_multi", "ft8gpu_decode_batch_multi_dev",
     "ft8_find_sync", "ft8_decode", "ft8_encode", "pack77",            # ft8_lib level (include/ft8_lib/ft8/*.h)
@@ -141,6 +142,12 @@ def _declare(L):
     L.ft8gpu_dev_alloc.restype = vp
     L.ft8gpu_dev_free.argtypes = [vp, vp]
     L.ft8gpu_dev_free.restype = None
+    if hasattr(L, "ft8gpu_host_alloc"):                   # absent from older builds loaded by load_library_at
+        L.ft8gpu_host_alloc.argtypes = [C.c_size_t]
+        L.ft8gpu_host_alloc.restype = vp
+        L.ft8gpu_host_free.argtypes = [vp]
+        L.ft8gpu_host_free.restype = None
+        L.ft8gpu_overlap_active.argtypes = [vp]
     L.ft8gpu_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
     L.ft8gpu_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
     L.initFFTW.restype = None
@@ -236,6 +243,11 @@ class Decoder:
 
     def set_debug_flags(self, flags):
         _check(self.lib.ft8gpu_set_debug_flags(self.h, int(flags)))
+
+    def overlap_active(self):
+        """True: the two-part pipeline with the serial kernels on side streams is in use for large batches (the
+        context has SEEN its streams run kernels concurrently); False: plain pipeline (last_error() says why)"""
+        return bool(self.lib.ft8gpu_overlap_active(self.h))
 
     def selftest_bp_math(self):
         """exhaustive (2^32 inputs) comparison of the BP kernel's short division chains with the IEEE quotient"""
@@ -397,6 +409,31 @@ def decode_batch_multi(decoders, iq, decodes=None):
     hs = (C.c_void_p * len(decoders))(*[d.h for d in decoders])
     _check(load_library().ft8gpu_decode_batch_multi(hs, len(decoders), iq.ctypes.data, B, decodes.ctypes.data, n.ctypes.data))
     return decodes, n
+
+
+class PinnedArray:
+    """numpy view of page-locked host memory from ft8gpu_host_alloc (freed by close() or at garbage collection)"""
+
+    def __init__(self, shape, dtype=np.float32):
+        lib = load_library()
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self.ptr = lib.ft8gpu_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise Ft8GpuError(lib.ft8gpu_last_error().decode(errors="replace"))
+        buf = (C.c_char * self.nbytes).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            load_library().ft8gpu_host_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def decode_batch_multi_dev(decoders, iq_devs, nframes, decodes=None):

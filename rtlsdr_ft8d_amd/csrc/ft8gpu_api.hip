@@ -110,6 +110,9 @@ struct ft8gpu_ctx {
                                            // while the main stream works on the other half
     hipStream_t side2 = nullptr;           // heap replay of part B (beside the one of part A on `side`)
     hipEvent_t dep[6]{};                   // cross-stream dependencies (no timing)
+    bool overlap_ok = false;               // main, side and side2 were SEEN to run kernels concurrently (probe_streams)
+    int *d_probe = nullptr;                // two ints for that probe
+    char overlap_why[160] = "";            // why the overlapped pipeline is off (empty when it is on)
     std::mutex mu;                         // every entry point holds it: concurrent callers of one context serialise
     unsigned debug_flags = 0;              // FT8GPU_DBG_* (test hooks, per context)
     hipStream_t copy = nullptr;            // host-buffer calls: uploads chunk k+1 while chunk k is decoded
@@ -191,6 +194,85 @@ float elapsed(hipEvent_t a, hipEvent_t b) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0.f;
     return ms;
+}
+
+// ---- do the context's streams really run kernels side by side? --------------------------------------------------------
+// The two-part pipeline below hides the serial kernels (heap replay, spot collection) under the throughput kernels of the
+// other part, which only works if the main stream and the two side streams sit on three different hardware queues: HIP
+// multiplexes streams onto a few queues, and streams that share one run their kernels one after the other (round 3 lost
+// 0.27 ms per step when the context happened to be created after a framework's streams).  Instead of relying on creation
+// order, the context MEASURES it: a one-wave kernel on stream A spins until a flag is set or 2 ms have passed, a
+// one-thread kernel on stream B sets the flag; A reports whether it saw it.  Side streams are created with the highest
+// stream priority (their kernels are short dependent chains that should never queue behind bulk work; HIP also keeps
+// queues of different priorities apart); one that does not co-run with the others is replaced by a newly created one
+// (the rejected stream is kept until the search ends so that its queue is not handed out again), a few times; if that
+// fails too the context runs the plain pipeline (one launch per stage, nothing on side streams) and says so:
+// ft8gpu_overlap_active() returns 0 and ft8gpu_last_error() holds the reason.
+__global__ void ft8_probe_wait_kernel(int *flag, int *seen, unsigned long long timeout_ticks) {
+    const unsigned long long t0 = wall_clock64();
+    int ok = 0;
+    do {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = 1; break; }
+        __builtin_amdgcn_s_sleep(16);
+    } while (wall_clock64() - t0 < timeout_ticks);
+    *seen = ok;
+}
+__global__ void ft8_probe_set_kernel(int *flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// 1: a kernel on `b` ran while a kernel on `a` was running; 0: it did not (within 2 ms); -1: HIP error (g_err set)
+int streams_corun(ft8gpu_ctx *c, hipStream_t a, hipStream_t b) {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000;
+    HIP_TRY(hipStreamSynchronize(a));
+    HIP_TRY(hipStreamSynchronize(b));
+    HIP_TRY(hipMemsetAsync(c->d_probe, 0, 2 * sizeof(int), a));
+    HIP_TRY(hipStreamSynchronize(a));
+    hipLaunchKernelGGL(ft8_probe_wait_kernel, dim3(1), dim3(1), 0, a, c->d_probe, c->d_probe + 1, (unsigned long long)khz * 2ull);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(ft8_probe_set_kernel, dim3(1), dim3(1), 0, b, c->d_probe);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(a));
+    HIP_TRY(hipStreamSynchronize(b));
+    int seen = 0;
+    HIP_TRY(hipMemcpy(&seen, c->d_probe + 1, sizeof(int), hipMemcpyDeviceToHost));
+    return seen ? 1 : 0;
+}
+
+hipError_t create_side_stream(hipStream_t *s, bool high_priority = true) {
+    int least = 0, greatest = 0;
+    if (!high_priority || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) greatest = 0;
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
+}
+
+// (re)establishes c->overlap_ok for the current main stream; replaces side streams that share a queue
+int probe_streams(ft8gpu_ctx *c) {
+    c->overlap_ok = false;
+    c->overlap_why[0] = 0;
+    if (!c->d_probe) HIP_TRY(hipMalloc(&c->d_probe, 2 * sizeof(int)));
+    std::vector<hipStream_t> rejected;
+    auto cleanup = [&] { for (hipStream_t r : rejected) (void)hipStreamDestroy(r); rejected.clear(); };
+    int rc = 1;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        // which of the side streams fails against the main stream or against its sibling?
+        int bad = 0;                                  // 1: side, 2: side2
+        if ((rc = streams_corun(c, c->stream, c->side)) < 0) break;
+        if (rc == 0) bad = 1;
+        if (!bad) { if ((rc = streams_corun(c, c->stream, c->side2)) < 0) break; if (rc == 0) bad = 2; }
+        if (!bad) { if ((rc = streams_corun(c, c->side, c->side2)) < 0) break; if (rc == 0) bad = 2; }
+        if (!bad) { c->overlap_ok = true; break; }
+        hipStream_t fresh = nullptr;
+        if (create_side_stream(&fresh, attempt < 3) != hipSuccess) { rc = 0; break; }    // later attempts: default priority (another pool of queues)
+        hipStream_t &slot = bad == 1 ? c->side : c->side2;
+        rejected.push_back(slot);
+        slot = fresh;
+        rc = 0;
+    }
+    cleanup();
+    if (rc < 0) return -1;
+    if (!c->overlap_ok)
+        snprintf(c->overlap_why, sizeof c->overlap_why,
+                 "the context's side streams do not run beside its main stream (shared hardware queues): plain pipeline, no overlap");
+    return 0;
 }
 
 // Large batches: the two serial kernels (exact heap replay, spot collection) keep only one lane per frame
@@ -285,7 +367,7 @@ int run_pipeline_overlapped(ft8gpu_ctx *c, const float *d_iq, int n, struct deco
 
 // the pipeline on device pointers; all intermediates in the context's HBM buffers
 int run_pipeline(ft8gpu_ctx *c, const float *d_iq, int n, struct decoder_results *d_dec, int32_t *d_nres) {
-    if (!(c->debug_flags & FT8GPU_DBG_NO_OVERLAP) && n >= 512) return run_pipeline_overlapped(c, d_iq, n, d_dec, d_nres);
+    if (c->overlap_ok && !(c->debug_flags & FT8GPU_DBG_NO_OVERLAP) && n >= 512) return run_pipeline_overlapped(c, d_iq, n, d_dec, d_nres);
     StageTimer t(c);
     const ft8gpu_params &p = c->params;
     t.mark(0);
@@ -329,8 +411,8 @@ static int create_body(ft8gpu_ctx *c) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
     for (auto &slot : c->ev) for (auto &e : slot) HIP_TRY(hipEventCreate(&e));
-    HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
+    HIP_TRY(create_side_stream(&c->side));
+    HIP_TRY(create_side_stream(&c->side2));
     for (auto &e : c->dep) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     // (the upload stream of the host-buffer path is created on first use: a context that only sees device pointers
     // keeps its three streams on three hardware queues of their own)
@@ -353,6 +435,7 @@ static int create_body(ft8gpu_ctx *c) {
     HIP_TRY(hipMalloc(&c->d_nres, F * sizeof(int32_t)));
     if (alloc_candidate_buffers(c, c->params.max_candidates < 120 ? 120 : c->params.max_candidates)) return -1;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (probe_streams(c)) return -1;
     return 0;
 }
 
@@ -395,7 +478,7 @@ void ft8gpu_destroy(ft8gpu_ctx *c) {
     void *bufs[] = { c->d_tab, c->d_iq, c->d_mag, c->d_lists, c->d_list_counts, c->d_cands, c->d_counts,
                      c->d_status, c->d_decodes, c->d_nres, c->d_scores, c->d_sigs,
                      c->d_rx_sums, c->d_rx_p2, c->d_rx_raw, c->d_rx_iq,
-                     c->d_rep, c->d_rep_len, c->d_rep_time };
+                     c->d_rep, c->d_rep_len, c->d_rep_time, c->d_probe };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->side) (void)hipStreamSynchronize(c->side);
     for (auto &slot : c->ev) for (auto &e : slot) if (e) (void)hipEventDestroy(e);
@@ -420,7 +503,17 @@ int ft8gpu_set_stream(ft8gpu_ctx *c, void *hip_stream) {
     if (c->own_stream) { (void)hipStreamDestroy(c->stream); c->own_stream = false; }
     if (hip_stream) c->stream = (hipStream_t)hip_stream;
     else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    // a borrowed stream may share a hardware queue with a side stream: measure again (and re-roll the side streams)
+    if (probe_streams(c)) return -1;
+    if (!c->overlap_ok) fail("%s", c->overlap_why);           // not an error: the call succeeds, the reason is on record
     return 0;
+}
+
+int ft8gpu_overlap_active(ft8gpu_ctx *c) {
+    if (!c) return fail("ctx is NULL");
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!c->overlap_ok) fail("%s", c->overlap_why);
+    return c->overlap_ok ? 1 : 0;
 }
 
 void *ft8gpu_get_stream(ft8gpu_ctx *c) {
@@ -444,8 +537,6 @@ int ft8gpu_set_params(ft8gpu_ctx *c, const ft8gpu_params *p) {
 int ft8gpu_set_debug_flags(ft8gpu_ctx *c, unsigned flags) {
     CHECK_COMMON(c, 0);
     if (flags & ~FT8GPU_DBG_ALL) return fail("ft8gpu_set_debug_flags: unknown bits 0x%x", flags & ~FT8GPU_DBG_ALL);
-    if ((flags & FT8GPU_DBG_WATERFALL_QUAD) && (flags & FT8GPU_DBG_WATERFALL_LDS))
-        return fail("ft8gpu_set_debug_flags: FT8GPU_DBG_WATERFALL_QUAD and FT8GPU_DBG_WATERFALL_LDS exclude each other");
     if ((flags & FT8GPU_DBG_HEAP_LANE_PER_FRAME) && (flags & FT8GPU_DBG_HEAP_WAVE_PER_FRAME))
         return fail("ft8gpu_set_debug_flags: FT8GPU_DBG_HEAP_LANE_PER_FRAME and FT8GPU_DBG_HEAP_WAVE_PER_FRAME exclude each other");
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -525,6 +616,17 @@ void ft8gpu_dev_free(ft8gpu_ctx *c, void *p) {
     Entry entry_(c);
     (void)hipFree(p);
 }
+// page-locked host memory: the host-buffer entries upload with hipMemcpyAsync, which is a true asynchronous DMA (and
+// overlaps the kernels of the previous chunk) only from pinned memory; from pageable memory it is staged through a
+// bounce buffer and serialises.  Plain hipHostMalloc / hipHostFree, offered here so that a C caller of the batch
+// entries needs no HIP header.
+void *ft8gpu_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { fail("hipHostMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+void ft8gpu_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
 int ft8gpu_memcpy_h2d(ft8gpu_ctx *c, void *d, const void *s, size_t n) {
     CHECK_COMMON(c, 0);
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -11,8 +11,8 @@
 //     0..511 are computed.  The inputs of that last stage differ in the LOWEST digit of the point index only, and the
 //     second layout puts that digit into the lane's ROW number (lane >> 4), so the second exchange is a 4 x 4
 //     transpose of registers across the four 16-lane rows of the wave: v_permlane16_swap + v_permlane32_swap (gfx950),
-//     one instruction per register, no LDS.  (Forms with that exchange through LDS, or inside the quads with DPP
-//     selects, are kept behind per-context debug flags: bit-identical, measured in DESIGN.md.)
+//     one instruction per register, no LDS.  (The form with that exchange through LDS is kept behind a per-context
+//     debug flag: bit-identical, measured in DESIGN.md.)
 //   * stage-0 twiddles live in registers, those of stages 1-3 (multiples of 4) in a 2 KB LDS table, the window is
 //     re-read from L1 per row: 37.9 KB of LDS and at most 128 VGPRs, i.e. four workgroups per CU.
 //   * the dB quantiser is evaluated against a 256-entry threshold table derived on the host from
@@ -22,7 +22,6 @@
 //   * arithmetic order of the FFT is the "R4DIF-1024" order documented in DESIGN.md; compiled with
 //     -ffp-contract=off so every float operation is a single IEEE operation.
 #include "ft8gpu_internal.h"
-#include "quad_transpose.h"
 #include <stdlib.h>
 
 namespace {
@@ -125,14 +124,18 @@ __device__ __forceinline__ int xcd_item(int step, int nframes) {
 //                registers across the four rows of the wave, which gfx950 does with v_permlane16_swap (odd rows of one
 //                register against even rows of another) and v_permlane32_swap (upper half against lower half): one
 //                instruction per register, 32 per row of the waterfall, no select masks, no LDS.
-//   kStage4Quad  round 3's form: the digit sits in the lane's position inside its quad, the transpose is two rounds of
-//                fused select + quad permute (quad_transpose.h), 64 instructions per row.
-//   kStage4Lds   the exchange through LDS (16 ds_write_b64 + 8 ds_read_b128 per row, XOR-swizzled layout below).
-// All three run the same butterflies in the same order: bit-identical output (test_waterfall_forms_are_bit_identical).
-constexpr int kStage4Rows = 0, kStage4Quad = 1, kStage4Lds = 2;
+//   kStage4Lds   round 3's product: the exchange through LDS (16 ds_write_b64 + 8 ds_read_b128 per row, XOR-swizzled
+//                layout below), digit in the low lane bits.  Kept behind FT8GPU_DBG_WATERFALL_LDS as an independent
+//                mechanism to hold the transposes against.
+// Both run the same butterflies in the same order: bit-identical output (test_waterfall_forms_are_bit_identical).
+// Measured, profiles/r04_waterfall_forms.json: 0.881 against 0.904 ms per 4096 frames alone, equal inside the pipeline;
+// LDS instruction path 0.92 -> 0.60 busy, VALU 0.62 -> 0.71, 433 against 406 VALU instructions per row.  (Round 3's third
+// form -- the same transpose inside the quads with fused select + quad permute, 64 instructions and hand-placed hazard
+// padding -- took the same time with 36 more instructions per row and was removed.)
+constexpr int kStage4Rows = 0, kStage4Lds = 2;
 
 // first exchange: point p of the row sits at complex slot p + PAD * (p >> 6).  Writes are lane-contiguous whatever PAD is;
-// the reads of the second layout want 4 b + j (quad / LDS forms: PAD 4) or 2 b + j (row form: PAD 2) to run through
+// the reads of the second layout want 4 b + j (LDS form: PAD 4) or 2 b + j (row form: PAD 2) to run through
 // all 32 eight-byte bank pairs within a 32-lane group.
 template <int PAD> __device__ __forceinline__ int pad_idx(int p) { return p + PAD * (p >> 6); }
 
@@ -150,22 +153,16 @@ __device__ __forceinline__ void row_transpose4(float &r0, float &r1, float &r2, 
     r3 = __uint_as_float(d[1]);
 }
 
-// Last radix-4 stage + quantiser + staging of the row's 512 output bytes, for the two forms without the second LDS
-// exchange.  After the transposes lane (b, j) holds all four inputs of the butterflies c = 16 b + 4 i + j, i = 0..3, in
-// registers 4i .. 4i+3.  Outputs are in digit-reversed order: butterfly c holds bins rev4(c) and 256 + rev4(c),
-// rev4(c) = (b >> 2) + 4 (b & 3) + 16 i + 64 j.
-template <int STAGE4>
+// Last radix-4 stage + quantiser + staging of the row's 512 output bytes for the row form.  After the transposes lane
+// (j, b) holds all four inputs of the butterflies c = 16 b + 4 i + j, i = 0..3, in registers 4i .. 4i+3.  Outputs are in
+// digit-reversed order: butterfly c holds bins rev4(c) and 256 + rev4(c), rev4(c) = (b >> 2) + 4 (b & 3) + 16 i + 64 j.
 __device__ __forceinline__ void stage4_in_registers(c32 (&x)[16], int b, int j, const float *s_thr, unsigned char *ob) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float r0 = x[4 * i].x, r1 = x[4 * i + 1].x, r2 = x[4 * i + 2].x, r3 = x[4 * i + 3].x;
         float m0 = x[4 * i].y, m1 = x[4 * i + 1].y, m2 = x[4 * i + 2].y, m3 = x[4 * i + 3].y;
-        if (STAGE4 == kStage4Quad) {
-            quad_transpose4x2(r0, r1, r2, r3, m0, m1, m2, m3);
-        } else {
-            row_transpose4(r0, r1, r2, r3);
-            row_transpose4(m0, m1, m2, m3);
-        }
+        row_transpose4(r0, r1, r2, r3);
+        row_transpose4(m0, m1, m2, m3);
         x[4 * i] = c32{ r0, m0 };
         x[4 * i + 1] = c32{ r1, m1 };
         x[4 * i + 2] = c32{ r2, m2 };
@@ -290,7 +287,7 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
         }
         if (STAGE4 != kStage4Lds) {
             wave_lds_sync();                            // every lane has read its stage-2 inputs out of xb: its front becomes the row's output bytes
-            stage4_in_registers<STAGE4>(x, b16, j2, s_thr, ob);
+            stage4_in_registers(x, b16, j2, s_thr, ob);
         } else {
 #pragma unroll
             for (int a = 0; a < 16; ++a) xb[wbase2[a & 3] + 8 * (a >> 2)] = make_float2(x[a].x, x[a].y);
@@ -330,7 +327,7 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
 
 }  // namespace
 
-// stage4: 0 = the product (row transposes), FT8GPU_DBG_WATERFALL_QUAD / FT8GPU_DBG_WATERFALL_LDS select the other forms
+// FT8GPU_DBG_WATERFALL_LDS selects the form with the second exchange through LDS; the product is the row-transpose form
 hipError_t launch_waterfall(const float *iq, uint8_t *mag, const Ft8Tables *tab, int nframes,
                             int num_cus, unsigned debug_flags, hipStream_t s) {
     const int nitems = nframes * kWfItemsPerFrame;
@@ -341,8 +338,6 @@ hipError_t launch_waterfall(const float *iq, uint8_t *mag, const Ft8Tables *tab,
     const int xo = (grid % 8 == 0 && nframes >= 64) ? 1 : 0;
     if (debug_flags & FT8GPU_DBG_WATERFALL_LDS)
         hipLaunchKernelGGL(ft8_waterfall_kernel<kStage4Lds>, dim3(grid), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xo);
-    else if (debug_flags & FT8GPU_DBG_WATERFALL_QUAD)
-        hipLaunchKernelGGL(ft8_waterfall_kernel<kStage4Quad>, dim3(grid), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xo);
     else
         hipLaunchKernelGGL(ft8_waterfall_kernel<kStage4Rows>, dim3(grid), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xo);
     return hipGetLastError();

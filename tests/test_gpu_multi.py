@@ -291,3 +291,65 @@ def test_multi_entry_keeps_its_worker_threads():
         for _ in range(5):
             ft8.decode_batch_multi([a, b, c], host)
         assert L.ft8gpu_shard_workers() == w
+
+
+# ---- the overlap does not depend on stream creation order ------------------------------------------------------------
+def test_overlap_survives_a_context_created_after_framework_streams():
+    """Round 3: a context created after a framework's streams shared hardware queues with them and lost 0.27 ms per
+    step.  The context now MEASURES whether its streams run kernels side by side (a 2 ms co-execution probe per pair
+    of streams at ft8gpu_create and at ft8gpu_set_stream) and replaces side streams that do not; so a context created
+    behind a crowd of busy framework streams must still report the overlapped pipeline, and the records must be the
+    ones of the plain pipeline."""
+    import torch
+    import rtlsdr_ft8d_amd as ft8
+    from rtlsdr_ft8d_amd import workload
+    crowd = [torch.cuda.Stream() for _ in range(9)]
+    for st in crowd:
+        with torch.cuda.stream(st):
+            torch.zeros(1024, device="cuda").sum()
+    torch.cuda.synchronize()
+    n = 1024
+    with ft8.Decoder(device=0, max_frames=n) as first, ft8.Decoder(device=0, max_frames=n) as dec:
+        assert first.overlap_active() and dec.overlap_active()
+        iq = _job(ft8, workload, dec, 40000, n)
+        spots = torch.zeros((n, 1400), dtype=torch.uint8, device="cuda")
+        nres = torch.zeros((n,), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        dec.decode_batch_dev(iq, n, spots, nres)
+        dec.synchronize()
+        a = (spots.cpu().numpy().tobytes(), nres.cpu().numpy().tobytes())
+        # a borrowed main stream is probed again; whatever the outcome, the records are the same
+        dec.set_stream(crowd[0].cuda_stream)
+        state = dec.overlap_active()
+        assert state in (True, False)
+        spots.zero_(); nres.zero_()
+        torch.cuda.synchronize()
+        dec.decode_batch_dev(iq, n, spots, nres)
+        dec.synchronize()
+        assert (spots.cpu().numpy().tobytes(), nres.cpu().numpy().tobytes()) == a
+        dec.set_stream(None)
+        assert dec.overlap_active()
+        dec.set_debug_flags(ft8.DBG_NO_OVERLAP)
+        spots.zero_(); nres.zero_()
+        torch.cuda.synchronize()
+        dec.decode_batch_dev(iq, n, spots, nres)
+        dec.synchronize()
+        assert (spots.cpu().numpy().tobytes(), nres.cpu().numpy().tobytes()) == a
+    assert int(np.frombuffer(a[1], np.int32).sum()) > 8 * n
+
+
+def test_host_entry_from_page_locked_memory_of_the_abi():
+    """ft8gpu_host_alloc / ft8gpu_host_free: the host-buffer batch entry fed from the library's own pinned memory gives
+    the records of the same frames fed from pageable memory"""
+    import rtlsdr_ft8d_amd as ft8
+    from rtlsdr_ft8d_amd import workload
+    n = 600                                                  # two upload chunks (512 + 88)
+    with ft8.Decoder(device=0, max_frames=n) as dec:
+        iq = _job(ft8, workload, dec, 50000, n).cpu().numpy()
+        d0, n0 = dec.decode_batch(iq)
+        pinned = ft8.PinnedArray(iq.shape, np.float32)
+        pinned.array[...] = iq
+        d1, n1 = dec.decode_batch(pinned.array)
+        pinned.close()
+    assert np.array_equal(n0, n1) and d0.tobytes() == d1.tobytes()
+    assert int(n1.sum()) > 8 * n

@@ -1,7 +1,7 @@
 export TMPDIR=/tmp
 CMD0="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-legs --no-clock-sampler"
-# FORMS: FT8GPU_DBG_* values selecting the last-stage form of the waterfall kernel: 0 rows (product), 8 quad, 16 lds
-for f in ${FORMS:-0 8 16}; do
+# FORMS: FT8GPU_DBG_* values selecting the last-stage form of the waterfall kernel: 0 rows (product), 8 lds
+for f in ${FORMS:-0 8}; do
   CMD="$CMD0 --debug-flags $f"
   rm -rf gpurun_out/wfpmc$f; mkdir -p gpurun_out/wfpmc$f
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d gpurun_out/wfpmc$f/sq -o sq -- $CMD > gpurun_out/wfpmc$f/sq.log 2>&1
