@@ -16,6 +16,7 @@
 #include "../../include/ft8_lib/ft8/encode.h"
 #include "ft8_tables.h"
 
+#include <errno.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdio.h>
@@ -322,66 +323,95 @@ void ft8gpu_encode(const uint8_t payload[10], uint8_t tones[FT8GPU_NN]) {
 }
 
 /* ---------------------------------------------------------------------------------------------
- * replay file formats, rtlsdr_ft8d.c:744-856
+ * replay file formats (what readRawIQfile / readC2file / writeRawIQfile of rtlsdr_ft8d.c:744-856 read and write)
+ *
+ *   .iq  up to 48000 records of two little-endian float32: (I, -Q)   -- Q is stored negated ("convention used by
+ *        wsprsim", :760); a short file gives a short frame, an odd trailing float is dropped (nread / 2, :756)
+ *   .c2  the same records behind a 26-byte header: 14 B name, int32 type, float64 dial frequency (:823-825)
+ * After loading, the frame is scaled so that its largest |I| or |Q| becomes 0.5 (:763-778: the peak starts at 1e-24f,
+ * the factor is the DOUBLE quotient 0.5 / peak rounded to float, the products are float).
+ * Streamed through a small block buffer (the reference puts 384 KB on the stack); the peak is taken while the records
+ * are split, so the file is walked once and the frame twice.
  * ------------------------------------------------------------------------------------------- */
-static int32_t load_interleaved(FILE *fd, float *iSamples, float *qSamples) {
-    float *buf = (float *)malloc(sizeof(float) * 2 * FT8GPU_NSAMPLES);
-    if (!buf) return 0;
-    const int32_t nread = (int32_t)fread(buf, sizeof(float), 2 * FT8GPU_NSAMPLES, fd);
-    const int32_t recsize = nread / 2;
-    for (int32_t i = 0; i < recsize; i++) {               /* :758-761 */
-        iSamples[i] = buf[2 * i];
-        qSamples[i] = -buf[2 * i + 1];
+enum { kRecordsPerBlock = 2048 };
+
+static FILE *open_or_complain(const char *path, const char *mode) {
+    FILE *f = fopen(path, mode);
+    if (!f) fprintf(stderr, "ft8gpu: cannot open %s (%s)\n", path, strerror(errno));
+    return f;
+}
+
+/* splits (I, -Q) records from `f` into the planar frame; returns the number of whole records */
+static int32_t split_records(FILE *f, float *plane_i, float *plane_q) {
+    float block[2 * kRecordsPerBlock];
+    int32_t have = 0;                       /* records stored so far */
+    float peak = 1e-24f;
+    while (have < FT8GPU_NSAMPLES) {
+        size_t want = 2 * (size_t)(FT8GPU_NSAMPLES - have);            /* always an even number of floats */
+        if (want > 2 * kRecordsPerBlock) want = 2 * kRecordsPerBlock;
+        const size_t got = fread(block, sizeof(float), want, f);
+        const int32_t whole = (int32_t)(got / 2);                       /* a dangling half record is dropped, as nread / 2 does */
+        for (int32_t r = 0; r < whole; r++) {
+            const float vi = block[2 * r], vq = -block[2 * r + 1];
+            plane_i[have + r] = vi;
+            plane_q[have + r] = vq;
+            const float ai = fabsf(vi), aq = fabsf(vq);
+            if (ai > peak) peak = ai;
+            if (aq > peak) peak = aq;
+        }
+        have += whole;
+        if (got < want) break;                                          /* end of file */
     }
-    free(buf);
-    float maxSig = 1e-24f;                                /* :763-778 */
-    for (int32_t i = 0; i < recsize; i++) {
-        const float absI = fabs(iSamples[i]), absQ = fabs(qSamples[i]);
-        if (absI > maxSig) maxSig = absI;
-        if (absQ > maxSig) maxSig = absQ;
+    const float gain = (float)(0.5 / (double)peak);
+    for (int32_t k = 0; k < have; k++) {
+        plane_i[k] *= gain;
+        plane_q[k] *= gain;
     }
-    maxSig = 0.5 / maxSig;
-    for (int32_t i = 0; i < recsize; i++) { iSamples[i] *= maxSig; qSamples[i] *= maxSig; }
-    return recsize;
+    return have;
 }
 
 int32_t ft8gpu_read_raw_iq(float *iSamples, float *qSamples, const char *filename) {
-    FILE *fd = fopen(filename, "rb");
-    if (!fd) { fprintf(stderr, "Cannot open data file...\n"); return 0; }
-    const int32_t r = load_interleaved(fd, iSamples, qSamples);
-    fclose(fd);
-    return r;
+    FILE *f = open_or_complain(filename, "rb");
+    if (!f) return 0;
+    const int32_t records = split_records(f, iSamples, qSamples);
+    fclose(f);
+    return records;
 }
 
 int32_t ft8gpu_read_c2(float *iSamples, float *qSamples, const char *filename, double *dialfreq) {
-    FILE *fd = fopen(filename, "rb");
-    if (!fd) { fprintf(stderr, "Cannot open data file...\n"); return 0; }
-    char name[15];
-    int type = 0;
-    double frequency = 0.0;
-    size_t n = fread(name, sizeof(char), 14, fd);         /* :823-825: 14 B name, int type, double freq */
-    n += fread(&type, sizeof(int), 1, fd);
-    n += fread(&frequency, sizeof(double), 1, fd);
-    (void)n;
-    if (dialfreq) *dialfreq = frequency;
-    const int32_t r = load_interleaved(fd, iSamples, qSamples);
-    fclose(fd);
-    return r;
+    FILE *f = open_or_complain(filename, "rb");
+    if (!f) return 0;
+    struct { char name[14]; int32_t type; double dial_hz; } head;
+    memset(&head, 0, sizeof head);
+    /* three reads, as the file has no padding between the fields; a truncated header leaves zeros */
+    if (fread(head.name, 1, sizeof head.name, f) == sizeof head.name && fread(&head.type, sizeof head.type, 1, f) == 1)
+        (void)!fread(&head.dial_hz, sizeof head.dial_hz, 1, f);
+    if (dialfreq) *dialfreq = head.dial_hz;
+    const int32_t records = split_records(f, iSamples, qSamples);
+    fclose(f);
+    return records;
 }
 
 int32_t ft8gpu_write_raw_iq(const float *iSamples, const float *qSamples, const char *filename) {
-    FILE *fd = fopen(filename, "wb");
-    if (!fd) { fprintf(stderr, "Cannot open data file...\n"); return 0; }
-    float *buf = (float *)malloc(sizeof(float) * 2 * FT8GPU_NSAMPLES);
-    if (!buf) { fclose(fd); return 0; }
-    for (int32_t i = 0; i < FT8GPU_NSAMPLES; i++) {       /* :793-796 */
-        buf[2 * i] = iSamples[i];
-        buf[2 * i + 1] = -qSamples[i];
+    FILE *f = open_or_complain(filename, "wb");
+    if (!f) return 0;
+    float block[2 * kRecordsPerBlock];
+    int32_t done = 0;
+    while (done < FT8GPU_NSAMPLES) {
+        int32_t n = FT8GPU_NSAMPLES - done;
+        if (n > kRecordsPerBlock) n = kRecordsPerBlock;
+        for (int32_t r = 0; r < n; r++) {
+            block[2 * r] = iSamples[done + r];
+            block[2 * r + 1] = -qSamples[done + r];
+        }
+        if (fwrite(block, 2 * sizeof(float), (size_t)n, f) != (size_t)n) break;
+        done += n;
     }
-    const int32_t nwrite = (int32_t)fwrite(buf, sizeof(float), 2 * FT8GPU_NSAMPLES, fd);
-    free(buf);
-    fclose(fd);
-    if (nwrite != 2 * FT8GPU_NSAMPLES) { fprintf(stderr, "Cannot write all the data!\n"); return 0; }
+    const int closed = fclose(f);
+    if (done != FT8GPU_NSAMPLES || closed != 0) {
+        fprintf(stderr, "ft8gpu: short write to %s (%d of %d records)\n", filename, (int)done, FT8GPU_NSAMPLES);
+        return 0;
+    }
     return FT8GPU_NSAMPLES;
 }
 

@@ -122,6 +122,15 @@ def test_replay_file_formats(ft8, oracle, tmp_path):
     short = str(tmp_path / "s.iq")
     open(short, "wb").write(open(p, "rb").read()[:8 * 1000])
     assert lib.ft8gpu_read_raw_iq(gi.ctypes.data, gq.ctypes.data, short.encode()) == 1000
+    # ragged files: a dangling half record is dropped (nread / 2, :756), sizes off the reader's block grid, and the
+    # peak normalisation of the part that was read -- all against the oracle's restatement of the reference loop
+    for nfloats in (2 * 2048 + 1, 2 * 2049, 2 * 4096 - 1, 7, 1, 0, 2 * 48000 + 6):
+        ragged = str(tmp_path / f"r{nfloats}.iq")
+        open(ragged, "wb").write((open(p, "rb").read() + b"\0" * 64)[:4 * nfloats])
+        gi[:] = 0; gq[:] = 0; oi[:] = 0; oq[:] = 0
+        got = lib.ft8gpu_read_raw_iq(gi.ctypes.data, gq.ctypes.data, ragged.encode())
+        assert got == oracle.lib().ft8o_read_raw_iq(fp(oi), fp(oq), ragged.encode()) == min(nfloats // 2, 48000)
+        assert np.array_equal(gi, oi) and np.array_equal(gq, oq), nfloats
     assert lib.ft8gpu_read_raw_iq(gi.ctypes.data, gq.ctypes.data, b"/nonexistent/file.iq") == 0
 
 
