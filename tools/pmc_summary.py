@@ -48,7 +48,7 @@ def main():
     ap.add_argument("paths", nargs="+")
     ap.add_argument("--traffic")
     ap.add_argument("--frames", type=int, default=4096)
-    ap.add_argument("--no-overlap", action="store_true", help="counters were collected with FT8GPU_OVERLAP=0 (or a batch below 512 frames): one launch per stage")
+    ap.add_argument("--no-overlap", action="store_true", help="counters were collected with FT8GPU_DBG_NO_OVERLAP (or a batch below 512 frames): one launch per stage")
     ap.add_argument("--config-key", default=None, help="store the figures under this key of an EXISTING traffic file (e.g. config4) instead of at its top level")
     ap.add_argument("--command", default="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-legs")
     args = ap.parse_args()
