@@ -202,10 +202,9 @@ float elapsed(hipEvent_t a, hipEvent_t b) {
 // multiplexes streams onto a few queues, and streams that share one run their kernels one after the other (round 3 lost
 // 0.27 ms per step when the context happened to be created after a framework's streams).  Instead of relying on creation
 // order, the context MEASURES it: a one-wave kernel on stream A spins until a flag is set or 2 ms have passed, a
-// one-thread kernel on stream B sets the flag; A reports whether it saw it.  Side streams are created with the highest
-// stream priority (their kernels are short dependent chains that should never queue behind bulk work; HIP also keeps
-// queues of different priorities apart); one that does not co-run with the others is replaced by a newly created one
-// (the rejected stream is kept until the search ends so that its queue is not handed out again), a few times; if that
+// one-thread kernel on stream B sets the flag; A reports whether it saw it.  A side stream that does not co-run with the
+// others is replaced by a newly created one (the rejected stream is kept until the search ends so that its queue is
+// not handed out again), a few times; if that
 // fails too the context runs the plain pipeline (one launch per stage, nothing on side streams) and says so:
 // ft8gpu_overlap_active() returns 0 and ft8gpu_last_error() holds the reason.
 __global__ void ft8_probe_wait_kernel(int *flag, int *seen, unsigned long long timeout_ticks) {
@@ -238,11 +237,12 @@ int streams_corun(ft8gpu_ctx *c, hipStream_t a, hipStream_t b) {
     return seen ? 1 : 0;
 }
 
-hipError_t create_side_stream(hipStream_t *s, bool high_priority = true) {
-    int least = 0, greatest = 0;
-    if (!high_priority || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) greatest = 0;
-    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
-}
+// Plain non-blocking streams, default priority.  (Measured in round 4: with the side streams at the highest stream
+// priority the pipeline alone runs exactly as fast -- 4.19 against 4.195 ms per 4096 frames -- but beside a one-rank RCCL
+// exchange on a framework stream it LOSES 0.8 ms per step (5.09 against 4.23-4.30 ms; 4.37 against 4.24 ms with the
+// context created after the process group): queues of different priorities are arbitrated against each other, and the
+// hand-offs between the main stream and the collective's stream pay for it.  So no priorities.)
+hipError_t create_side_stream(hipStream_t *s) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
 
 // (re)establishes c->overlap_ok for the current main stream; replaces side streams that share a queue
 int probe_streams(ft8gpu_ctx *c) {
@@ -261,7 +261,7 @@ int probe_streams(ft8gpu_ctx *c) {
         if (!bad) { if ((rc = streams_corun(c, c->side, c->side2)) < 0) break; if (rc == 0) bad = 2; }
         if (!bad) { c->overlap_ok = true; break; }
         hipStream_t fresh = nullptr;
-        if (create_side_stream(&fresh, attempt < 3) != hipSuccess) { rc = 0; break; }    // later attempts: default priority (another pool of queues)
+        if (create_side_stream(&fresh) != hipSuccess) { rc = 0; break; }
         hipStream_t &slot = bad == 1 ? c->side : c->side2;
         rejected.push_back(slot);
         slot = fresh;

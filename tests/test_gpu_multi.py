@@ -7,6 +7,7 @@
   pipeline, records exchanged with workload.SpotExchange (gloo on CPU tensors: RCCL refuses two ranks on
   one device), gathered result byte-identical to the single-process batch.
 """
+import json
 import os
 import socket
 import sys
@@ -353,3 +354,42 @@ def test_host_entry_from_page_locked_memory_of_the_abi():
         pinned.close()
     assert np.array_equal(n0, n1) and d0.tobytes() == d1.tobytes()
     assert int(n1.sum()) > 8 * n
+
+
+def test_fallback_to_the_plain_pipeline_when_streams_cannot_co_run():
+    """With only two hardware queues for the process (GPU_MAX_HW_QUEUES=2, a documented HIP runtime setting) three
+    streams cannot all run side by side: the co-execution probe must notice, the context must run the plain pipeline
+    and say why, and the records must be the ones a normal process produces."""
+    import hashlib
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, hashlib, json
+sys.path.insert(0, os.environ["FT8_ROOT"])
+import torch, numpy as np
+import rtlsdr_ft8d_amd as ft8
+from rtlsdr_ft8d_amd import workload
+n = 768
+with ft8.Decoder(device=0, max_frames=n) as dec:
+    active = dec.overlap_active()
+    why = ft8.load_library().ft8gpu_last_error().decode()
+    _, tones = workload.message_pool()
+    sig, _ = workload.frame_signals(60000, n, 20, tones)
+    iq = torch.empty((n, 2, ft8.NSAMPLES), dtype=torch.float32, device="cuda")
+    dec.synth_frames(sig, n, 20, 1.0, workload.SEED_BASE, iq, first_frame=60000)
+    spots = torch.zeros((n, 1400), dtype=torch.uint8, device="cuda"); nres = torch.zeros((n,), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    dec.decode_batch_dev(iq, n, spots, nres); dec.synchronize()
+    print("RESULT", json.dumps({"active": active, "why": why, "digest": hashlib.sha256(spots.cpu().numpy().tobytes() + nres.cpu().numpy().tobytes()).hexdigest(),
+                                "messages": int(nres.sum().item())}))
+'''
+    res = {}
+    for queues in ("2", "4"):
+        env = dict(os.environ, GPU_MAX_HW_QUEUES=queues, FT8_ROOT=ROOT)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")]
+        assert line, out.stdout[-2000:] + out.stderr[-2000:]
+        res[queues] = json.loads(line[0][7:])
+    assert res["4"]["active"] is True
+    assert res["2"]["active"] is False and "plain pipeline" in res["2"]["why"], res["2"]
+    assert res["2"]["digest"] == res["4"]["digest"] and res["4"]["messages"] > 8 * 768
