@@ -618,14 +618,18 @@ def pmc_figures(kernel, frames, launches, ms_per_launch, config=2):
         return none
     sect = t if config == 2 else t.get(f"config{config}", {})
     e = sect.get(kernel, {})
-    if not e or e.get("frames_per_launch") != frames // launches or t.get("csrc_sha") != csrc_hash():
+    if not e or "hbm_bytes_per_frame" not in e or t.get("csrc_sha") != csrc_hash():
         return none
-    traffic = int(e["hbm_bytes_per_launch"])
-    insts = e.get("SQ_INSTS_VALU")
+    # The counter passes serialise kernels, so the context's co-execution probe selects the plain pipeline there (one
+    # launch per stage and batch); per-frame figures are what carries over to this run's launches of frames // launches.
+    per_launch = frames // launches
+    traffic = int(round(e["hbm_bytes_per_frame"] * per_launch))
+    insts = e.get("valu_instructions_per_frame")
     return {"traffic": traffic, "valu_busy": e.get("valu_busy_frac"),
-            "valu_frac": round(insts * 64 / (ms_per_launch * 1e-3) / FP32_VALU_PEAK, 4) if insts else None,
+            "valu_frac": round(insts * per_launch * 64 / (ms_per_launch * 1e-3) / FP32_VALU_PEAK, 4) if insts else None,
             "kernel_hbm_GBps": round(traffic / (ms_per_launch * 1e-3) / 1e9, 1),
-            "pmc_from": f"profiles/pmc_traffic.json{'' if config == 2 else ' [config%d]' % config} @ csrc {t.get('csrc_sha')}"}
+            "pmc_from": f"profiles/pmc_traffic.json{'' if config == 2 else ' [config%d]' % config} @ csrc {t.get('csrc_sha')}"
+                        f" (per-frame counters of {e.get('frames_per_launch')}-frame launches x {per_launch} frames)"}
 
 
 def usable_cores():

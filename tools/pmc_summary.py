@@ -33,7 +33,8 @@ def csrc_hash():
 KERNELS = ("ft8_decode_kernel", "ft8_waterfall_kernel", "ft8_sync_kernel", "ft8_heap_simt_kernel", "ft8_heap_kernel", "ft8_spots_kernel",
            "ft8_synth_kernel", "ft8_rx_block_kernel")
 WIDE = {"waterfall", "sync", "rx_block"}
-HALF_BATCH = {"waterfall", "sync", "heap", "heap_simt", "decode", "spots"}      # two launches per batch (a small first part and the rest): the mean per launch covers half a batch
+PER_FRAME = {"waterfall", "sync", "heap", "heap_simt", "decode", "spots"}       # kernels whose launches cover a number of frames (read off the sync kernel's grid)
+SYNC_THREADS_PER_FRAME = 4 * 2 * 512                                            # ft8_sync_kernel: 4 segments x 2 halves x 512 threads per frame
 
 
 def short(name):
@@ -48,11 +49,12 @@ def main():
     ap.add_argument("paths", nargs="+")
     ap.add_argument("--traffic")
     ap.add_argument("--frames", type=int, default=4096)
-    ap.add_argument("--no-overlap", action="store_true", help="counters were collected with FT8GPU_DBG_NO_OVERLAP (or a batch below 512 frames): one launch per stage")
+    ap.add_argument("--no-overlap", action="store_true", help="(ignored since round 4: the frames a launch covers are read off the sync kernel's grid size)")
     ap.add_argument("--config-key", default=None, help="store the figures under this key of an EXISTING traffic file (e.g. config4) instead of at its top level")
     ap.add_argument("--command", default="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-legs")
     args = ap.parse_args()
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    sync_grids = []
     for p in args.paths:
         with open(p) as f:
             for row in csv.DictReader(f):
@@ -60,6 +62,13 @@ def main():
                 if k is None:
                     continue
                 acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                if k == "sync":
+                    sync_grids.append(int(row["Grid_Size"]))
+    # Frames per launch.  rocprofv3's counter passes serialise kernels, so the context's co-execution probe
+    # (ft8gpu_overlap_active) reports that its streams do not run side by side and the PLAIN pipeline runs: one launch per
+    # stage for the whole batch.  Without that (older builds, other tools) the two-part pipeline gives two launches per
+    # batch.  Either way the mean number of frames per launch is what the sync kernel's grid says.
+    frames_per_launch = int(round(sum(sync_grids) / len(sync_grids) / SYNC_THREADS_PER_FRAME)) if sync_grids else args.frames
     out = {}
     for k, d in acc.items():
         out[k] = {c: sum(v) / len(v) for c, v in d.items()}
@@ -73,16 +82,20 @@ def main():
             if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v or k == "synth":
                 continue
             f, w = v["FETCH_SIZE"] * 1024, v["WRITE_SIZE"] * 1024
-            frames = args.frames // 2 if (k in HALF_BATCH and not args.no_overlap) else args.frames
+            frames = frames_per_launch if k in PER_FRAME else args.frames
+            hbm = int((2 * f if k in WIDE else f) + w)
             t[k] = {"fetch_size_kb_raw": round(v["FETCH_SIZE"], 1), "write_size_kb_raw": round(v["WRITE_SIZE"], 1),
                     "fetch_correction": "x2 (16 B/lane coalesced stream)" if k in WIDE else "x1 (byte/dword gathers: uncalibrated pattern, raw counter)",
-                    "hbm_bytes_per_launch": int((2 * f if k in WIDE else f) + w), "frames_per_launch": frames}
+                    "hbm_bytes_per_launch": hbm, "frames_per_launch": frames, "hbm_bytes_per_frame": round(hbm / frames, 1),
+                    "write_bytes_per_frame": round(w / frames, 1)}
             if "SQ_ACTIVE_INST_VALU" in v and "GRBM_GUI_ACTIVE" in v:
                 # SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves; GRBM_GUI_ACTIVE is summed over the 8 XCDs
                 t[k]["valu_busy_frac"] = round(v["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * v["GRBM_GUI_ACTIVE"] / 8), 3)
             for cn in ("SQ_INSTS_VALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
                 if cn in v:
                     t[k][cn] = v[cn]
+            if "SQ_INSTS_VALU" in v:
+                t[k]["valu_instructions_per_frame"] = round(v["SQ_INSTS_VALU"] / frames, 1)
         if args.config_key:
             whole = json.load(open(args.traffic))
             if whole.get("csrc_sha") != t["csrc_sha"]:
