@@ -22,10 +22,11 @@ def test_no_kernel_uses_scratch_and_no_dpp_follows_a_cmpx(tmp_path):
     assert d["problems"] == []
     ks = {k["kernel"]: k for k in d["kernels"]}
     # the kernels of the hot path are all there, and the LDPC kernel keeps eight waves per SIMD
-    for name in ("ft8_waterfall_kernel_v2<false>", "ft8_sync_kernel<false>", "ft8_heap_kernel", "ft8_heap_simt_kernel",
+    for name in ("ft8_waterfall_kernel<0>", "ft8_sync_kernel<false>", "ft8_heap_kernel", "ft8_heap_simt_kernel",
                  "ft8_decode_kernel<false, 3>", "ft8_decode_kernel<true, 1>", "ft8_spots_kernel"):
         assert name in ks, (name, sorted(ks))
         assert ks[name]["scratch_bytes_per_lane"] == 0
     assert ks["ft8_decode_kernel<false, 3>"]["waves_per_simd_by_vgprs"] == 8
     assert ks["ft8_decode_kernel<false, 3>"]["sgprs"] <= 80          # 256-thread workgroups: 8 per CU only up to 80 SGPRs
-    assert ks["ft8_waterfall_kernel_v2<false>"]["waves_per_simd_by_vgprs"] >= 4
+    # four waves of at most 120 registers leave 32 per lane free: the heap replay's waves run beside the waterfall kernel
+    assert ks["ft8_waterfall_kernel<0>"]["vgprs"] <= 120 and ks["ft8_waterfall_kernel<0>"]["waves_per_simd_by_vgprs"] == 4
