@@ -413,6 +413,9 @@ def main():
                       "slowest_step_index": int(np.argmax(per_step)),
                       "note": "hipEvent time between consecutive steps' last kernels on rank 0's stream"}
     out["gpu_clock"] = clk.summary()
+    pw = (out["gpu_clock"] or {}).get("power_w_median")
+    if pw:   # the LDPC kernel runs power-limited: energy per frame is the other side of frames/s (rank 0's GPU, socket power from hwmon)
+        out["gpu_clock"]["frames_per_joule"] = round((total / max(world, 1)) * args.steps / elapsed / pw, 1)
     out["prewarm_steps"] = args.prewarm        # untimed, before the W warm-up steps (clock ramp after idle; see --prewarm)
     out["config"]["decoded_messages_per_frame"] = round(float(nres.cpu().numpy().mean()), 2)
     if use_dist and world > 1:
