@@ -256,6 +256,74 @@ def test_unpack_all_message_types(oracle, gpu_decoder):
     assert len(texts) >= 6            # several distinct message shapes were produced
 
 
+def test_unpack_randomised_payload_sweep(oracle):
+    """6000 random 77-bit payloads -- uniformly random bits, and random bits with every i3 / n3 type, the special n28
+    tokens and the grid / report codes forced in -- painted 24 to a frame and decoded through the pipeline form's
+    neighbour (ft8gpu_decode_candidates): status, CRC, unpack return code and text of every one against the oracle.
+    (Round 4 rewrote the device unpack77 on two 64-bit words and an LDS work area: no byte array, no scratch.)"""
+    import rtlsdr_ft8d_amd as ft8
+    rng = np.random.default_rng(2026)
+    per_frame, nframes = 24, 250
+    n = per_frame * nframes
+    payloads = rng.integers(0, 256, (n, 10), dtype=np.uint8)
+    payloads[:, 9] &= 0xF8
+    forced = rng.random(n) < 0.7
+    i3 = rng.choice([0, 0, 1, 1, 1, 2, 2, 3, 4, 4, 5, 6, 7], n)
+    payloads[forced, 9] = (payloads[forced, 9] & 0xC0) | (i3[forced] << 3).astype(np.uint8)
+    tokens = np.array([0, 1, 2, 3, 4, 500, 1002, 1003, 1004, 20000, 532443, 532444, 2063591, 2063592, 2063593, 3000000,
+                       6257895, 6257896, 6257897, 10222009, 268435455], np.int64)
+    grids = np.array([0, 1, 17, 10320, 32399, 32400, 32401, 32402, 32403, 32404, 32405, 32406, 32430, 32435, 32436, 32470, 32767], np.int64)
+    for k in np.nonzero(forced)[0]:
+        p = payloads[k]
+        t = int(i3[k])
+        if t == 0:
+            n3 = int(rng.choice([0, 5, 0, 5, 1, 2, 3, 4, 6, 7]))
+            p[8] = (p[8] & 0xFE) | ((n3 >> 2) & 1)
+            p[9] = (p[9] & 0x3F) | ((n3 & 3) << 6)
+        if t in (1, 2):
+            if rng.random() < 0.5:
+                n29 = (int(rng.choice(tokens)) << 1) | int(rng.integers(0, 2))
+                p[0], p[1], p[2] = (n29 >> 21) & 0xFF, (n29 >> 13) & 0xFF, (n29 >> 5) & 0xFF
+                p[3] = (p[3] & 0x07) | ((n29 << 3) & 0xF8)
+            if rng.random() < 0.5:
+                n29 = (int(rng.choice(tokens)) << 1) | int(rng.integers(0, 2))
+                p[3] = (p[3] & 0xF8) | ((n29 >> 26) & 0x07)
+                p[4], p[5], p[6] = (n29 >> 18) & 0xFF, (n29 >> 10) & 0xFF, (n29 >> 2) & 0xFF
+                p[7] = (p[7] & 0x3F) | ((n29 & 3) << 6)
+            if rng.random() < 0.6:
+                ig = int(rng.choice(grids))
+                p[7] = (p[7] & 0xE0) | ((ig >> 10) & 0x1F)
+                p[8] = (ig >> 2) & 0xFF
+                p[9] = (p[9] & 0x3F) | ((ig & 3) << 6)
+    mags = np.full((nframes, 92, 2, 2, 256), 60, np.uint8)
+    cd = np.dtype([("score", "<i2"), ("time_offset", "<i2"), ("freq_offset", "<i2"), ("time_sub", "u1"), ("freq_sub", "u1")])
+    cands = np.zeros((nframes, 120), cd)
+    counts = np.full(nframes, per_frame, np.int32)
+    sym = np.arange(79)
+    for k in range(n):
+        f, c = divmod(k, per_frame)
+        f0 = 4 + 10 * c
+        tones = oracle.encode(np.ascontiguousarray(np.concatenate([payloads[k], np.zeros(2, np.uint8)])))
+        mags[f, sym, 0, 0, f0 + np.asarray(tones, np.int64)] = 170
+        cands[f, c] = (40, 0, f0, 0, 0)
+    mags = mags.reshape(nframes, MAG)
+    with ft8.Decoder(device=0, max_frames=nframes) as dec:
+        assert cands.dtype.itemsize == dec.find_sync(mags[:1])[0].dtype.itemsize
+        st = dec.decode_candidates(mags, cands.view(dec.find_sync(mags[:1])[0].dtype), counts)
+    kinds, oks = set(), 0
+    for f in range(nframes):
+        ref = _oracle_status(oracle, mags[f], cands[f, :per_frame], 20)
+        _compare_status(f"sweep frame {f}", st[f], ref)
+        for c, r in enumerate(ref):
+            assert r["ldpc_errors"] == 0
+            oks += int(r["ok"])
+            if r["ok"]:
+                kinds.add(r["text"].split(" ")[0][:2])
+            else:
+                assert bytes(st[f][c]["text"]).strip(b"\0") == b"", (f, c)       # no characters of a failed unpack leak into the record
+    assert oks > 0.4 * n and len(kinds) >= 12, (oks, sorted(kinds))
+
+
 def test_end_to_end_spots_exact(oracle, gpu_decoder, frames):
     iq = np.stack([f for _, f in frames])
     dec, n = gpu_decoder.decode_batch(iq)
