@@ -202,7 +202,7 @@ def test_config4_32768_frames_eight_shards(oracle):
     are eight contexts on GPU 0 (own streams and HBM buffers each; 12.6 GB of IQ resident), decoded through
     ft8gpu_decode_batch_multi_dev (eight host threads, records gathered at their frame offsets), and must be
     byte-identical to ONE 4096-frame context walking the same 32 768 frames chunk by chunk; the oracle agrees on
-    512 frames spread over all shards; about 12 messages decode per frame."""
+    every one of the 32 768 frames; about 12 messages decode per frame."""
     import torch
     import rtlsdr_ft8d_amd as ft8
     from rtlsdr_ft8d_amd import workload
@@ -231,16 +231,19 @@ def test_config4_32768_frames_eight_shards(oracle):
             assert spots.cpu().numpy().tobytes() == got[g * B:(g + 1) * B].tobytes(), f"shard {g}: records"
         per_frame = float(got_n.mean())
         assert 11.0 < per_frame < 13.5, per_frame
-        # the oracle on 512 frames, 64 per shard, spread evenly over each shard (round 3: 32 frames)
+        # the oracle on ALL 32 768 frames (round 3: 32 frames; about 13 s of the box's 16 usable host cores), shard by
+        # shard in 1024-frame chunks so that the host copy stays at 393 MB
         import bench
         nt = bench.usable_cores()
+        bad = []
         for g in range(S):
-            ks = [(j * B) // 64 for j in range(64)]
-            rdec, rn = oracle.subsystem_batch(shards[g][ks].cpu().numpy(), nthreads=nt)
-            for j, k in enumerate(ks):
-                f = g * B + k
-                assert got_n[f] == rn[j], f
-                assert got[f].tobytes() == rdec[j].tobytes(), f
+            for k0 in range(0, B, 1024):
+                rdec, rn = oracle.subsystem_batch(shards[g][k0:k0 + 1024].cpu().numpy(), nthreads=nt)
+                f0 = g * B + k0
+                for j in range(1024):
+                    if got_n[f0 + j] != rn[j] or got[f0 + j].tobytes() != rdec[j].tobytes():
+                        bad.append(f0 + j)
+        assert not bad, f"{len(bad)} of {total} frames differ from the oracle, first {bad[:8]}"
     finally:
         for d in decs:
             d.close()
