@@ -498,8 +498,9 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
     }
     // The 48-byte record is composed in the wave's LDS tile (the LLR area is free now) and leaves as one contiguous
     // 12-dword burst.  Nothing of it lives in private memory: min_errors, iter and the ballot words are wave-uniform
-    // scalars, the bytes of a91 are shifts of two 64-bit words, and unpack77 works on those words and on a work area
-    // behind the record -- the kernel has no scratch segment (tools/isa_census.py and tests/test_abi.py check it).
+    // scalars, the bytes of a91 are shifts of two 64-bit words, and unpack77 works on those words and stores the characters
+    // it computes (in registers) straight into the record's text -- the kernel has no scratch segment and the epilogue
+    // never waits for a load (tools/kernel_resources.py, tests/test_kernel_resources.py).
     static_assert(sizeof(ft8gpu_decode_status) == 48, "record is 12 dwords");
     static_assert(offsetof(ft8gpu_decode_status, a91) == 10 && offsetof(ft8gpu_decode_status, text) == 22, "record layout");
     uint32_t *rec32 = reinterpret_cast<uint32_t *>(llr);
@@ -524,8 +525,7 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
         if (lane == 0) {
             rec32[1] = crc_extracted | (crc_calc << 16);
             if (crc_extracted == crc_calc) {
-                ft8dev::UnpackWork *wk = reinterpret_cast<ft8dev::UnpackWork *>(rec + 64);
-                const int rc = ft8dev::unpack77(w0, w1 & 0xFFF8000000000000ull, rec + offsetof(ft8gpu_decode_status, text), wk);
+                const int rc = ft8dev::unpack77(w0, w1 & 0xFFF8000000000000ull, rec + offsetof(ft8gpu_decode_status, text));   // (text bytes are zero: see above)
                 if (rc < 0) {
                     // a failed unpack may have left characters behind: text is all zeros unless ok
                     rec32[5] &= 0xFFFFu;
