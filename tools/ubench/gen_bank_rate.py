@@ -65,6 +65,23 @@ packed("v_pk_fma_f32 d,d,a,b a,b other", "v_pk_fma_f32 {d}, {d}, {a}, {b}", (1, 
 packed("v_pk_fma_f32 d,a,b,c sources alternate", "v_pk_fma_f32 {d}, {a}, {b}, {c}", (0, 1, 0))
 packed("v_pk_mul_f32 d,d,b op_sel_hi:[1,0] b other", "v_pk_mul_f32 {d}, {d}, {a} op_sel_hi:[1,0]", (1, 0, 0))
 
+# dependency vs in-place: d_i = d_(i+1) * b reads a register another instruction of the block writes (a chain through the
+# loop), but never its own destination
+def chained(name, op, pk):
+    ins = []
+    for i in range(16):
+        j = (i + 1) % 16
+        if pk:
+            ins.append(f"{op} v[{40 + 2 * i}:{41 + 2 * i}], v[{40 + 2 * j}:{41 + 2 * j}], v[{72 + 2 * ((i + 1) % 2)}:{73 + 2 * ((i + 1) % 2)}]")
+        else:
+            ins.append(f"{op} v{40 + i}, v{40 + j}, v{72 + (i + 1) % 4}")
+    variants.append((name, ins))
+
+
+chained("v_mul_f32 d_i = d_(i+1) * b   (chained, not in place)", "v_mul_f32", False)
+chained("v_pk_mul_f32 d_i = d_(i+1) * b   (chained, not in place)", "v_pk_mul_f32", True)
+chained("v_pk_add_f32 d_i = d_(i+1) + b   (chained, not in place)", "v_pk_add_f32", True)
+
 src = ['// GENERATED by tools/ubench/gen_bank_rate.py -- do not edit', '#include <hip/hip_runtime.h>', '#include <stdio.h>',
        '#define N_ITERS 4096', f'#define CLOB {CLOB}', '']
 for k, (name, ins) in enumerate(variants):
