@@ -396,3 +396,28 @@ with ft8.Decoder(device=0, max_frames=n) as dec:
     assert res["4"]["active"] is True
     assert res["2"]["active"] is False and "plain pipeline" in res["2"]["why"], res["2"]
     assert res["2"]["digest"] == res["4"]["digest"] and res["4"]["messages"] > 8 * 768
+
+
+def test_c_node_bench_both_gather_forms(tmp_path):
+    """examples/ft8_node_bench.c: the multi-GPU entries driven from plain C (no HIP header) -- one context per GPU, shards
+    synthesised in HBM, host gather through ft8gpu_decode_batch_multi_dev and device-resident gather through
+    ft8gpu_gather_spots (RCCL).  With the box's one GPU both forms must run and leave the same list (FNV-1a of counts and
+    records), with a sensible number of messages per frame; two GPUs are refused when only one is visible."""
+    import subprocess
+    exe = str(tmp_path / "ft8_node_bench")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "ft8_node_bench.c"),
+                           "-L", os.path.join(ROOT, "rtlsdr_ft8d_amd"), "-lft8gpu",
+                           "-Wl,-rpath," + os.path.join(ROOT, "rtlsdr_ft8d_amd"), "-lm", "-o", exe])
+    res = []
+    for extra in ([], ["-r"]):
+        out = subprocess.run([exe, "-g", "1", "-f", "640", "-s", "2", *extra], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+        res.append(json.loads(out.stdout.strip().splitlines()[-1]))
+    assert res[0]["list_fnv1a"] == res[1]["list_fnv1a"], res
+    assert res[0]["overlap"] is True and 8.0 < res[0]["messages_per_frame"] < 16.0, res[0]
+    assert "host arrays" in res[0]["gather"] and "rccl" in res[1]["gather"]
+    import rtlsdr_ft8d_amd as ft8
+    if ft8.load_library().ft8gpu_device_count() == 1:
+        out = subprocess.run([exe, "-g", "2", "-f", "64", "-s", "1"], capture_output=True, text=True, timeout=600)
+        assert out.returncode != 0 and "not present" in out.stderr
