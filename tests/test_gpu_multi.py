@@ -421,3 +421,35 @@ def test_c_node_bench_both_gather_forms(tmp_path):
     if ft8.load_library().ft8gpu_device_count() == 1:
         out = subprocess.run([exe, "-g", "2", "-f", "64", "-s", "1"], capture_output=True, text=True, timeout=600)
         assert out.returncode != 0 and "not present" in out.stderr
+
+
+def test_context_lifecycle_does_not_leak_device_memory():
+    """ft8gpu_create / ft8gpu_destroy forty times (each context decodes a batch through the overlapped pipeline, grows its
+    host-path staging, the RX and report scratch are left unused): the device's free memory returns to where it was --
+    streams, events, the probe's words and every lazily grown buffer are released."""
+    import torch
+    import rtlsdr_ft8d_amd as ft8
+    from rtlsdr_ft8d_amd import workload
+    n = 512
+    with ft8.Decoder(device=0, max_frames=n) as dec:
+        iq = _job(ft8, workload, dec, 70000, n)
+        host = iq[:32].cpu().numpy()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    ref = None
+    for _ in range(40):
+        with ft8.Decoder(device=0, max_frames=n) as dec:
+            assert dec.overlap_active()
+            spots = torch.zeros((n, 1400), dtype=torch.uint8, device="cuda")
+            nres = torch.zeros((n,), dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            dec.decode_batch_dev(iq, n, spots, nres)
+            dec.synchronize()
+            d, k = dec.decode_batch(host)                      # host path: staging buffer + copy stream
+            digest = (spots.cpu().numpy().tobytes(), nres.cpu().numpy().tobytes(), d.tobytes(), k.tobytes())
+            assert ref is None or digest == ref
+            ref = digest
+            del spots, nres
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, (free0, free1)           # torch's caching allocator may keep a block; a leak of 40 contexts would be GBs
