@@ -32,6 +32,7 @@
 #include "ft8_tables.h"
 #include "unpack_dev.h"
 #include "bp_math.h"
+#include "ldpc_lds_layout.h"
 #include <stddef.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -555,7 +556,8 @@ hipError_t decode_tables_init(hipStream_t s) {
                 int pos = -1;
                 for (int j = 0; j < kFT8_Num_rows[m]; ++j)
                     if (kFT8_Nm[m][j] - 1 == n) pos = j;
-                h.edge_slot[r][l][e] = (uint16_t)slot_index(m, pos);
+                // the row's place in the LDS tile comes from the conflict-minimising layout (ldpc_lds_layout.h); its members keep their order
+                h.edge_slot[r][l][e] = (uint16_t)slot_index(kLdsRowPos[m], pos);
             }
         }
     for (int rr = 0; rr < 2; ++rr)
@@ -570,12 +572,18 @@ hipError_t decode_tables_init(hipStream_t s) {
             }
         }
     {
-        int n6 = 0, n7 = 0;
-        for (int l = 0; l < 64; ++l) h.own6[l] = h.own7[l] = (uint8_t)(kRows - 1);
-        for (int m = 0; m < kLdpcM; ++m) {
-            if (kFT8_Num_rows[m] == 7) { if (n7 >= 64) abort(); h.own7[n7++] = (uint8_t)m; }
-            else { if (n6 >= 64) abort(); h.own6[n6++] = (uint8_t)m; }
+        // which lane multiplies which row: also from the layout search (the float4 accesses of the owners want distinct positions
+        // mod 16 within their lane groups).  Checked here: every row is owned exactly once by a lane of the right kind, every
+        // position is used once, the spare position stays spare.
+        int owned[kLdpcM] = { 0 }, used[kRows] = { 0 };
+        for (int l = 0; l < 64; ++l) {
+            h.own6[l] = h.own7[l] = (uint8_t)(kRows - 1);
+            const int m6 = kOwn6Row[l], m7 = kOwn7Row[l];
+            if (m6 != 255) { if (m6 >= kLdpcM || kFT8_Num_rows[m6] != 6) abort(); h.own6[l] = kLdsRowPos[m6]; ++owned[m6]; }
+            if (m7 != 255) { if (m7 >= kLdpcM || kFT8_Num_rows[m7] != 7) abort(); h.own7[l] = kLdsRowPos[m7]; ++owned[m7]; }
         }
+        for (int m = 0; m < kLdpcM; ++m) { if (owned[m] != 1 || kLdsRowPos[m] >= kRows - 1 || used[kLdsRowPos[m]]++) abort(); }
+        if (kLdsRowPos[kRows - 1] != kRows - 1) abort();
     }
     for (int G = 1; G <= kMaxCheckGroups; ++G) {
         for (int g = 0; g < kMaxCheckGroups; ++g)
