@@ -584,6 +584,12 @@ hipError_t decode_tables_init(hipStream_t s) {
         }
         for (int m = 0; m < kLdpcM; ++m) { if (owned[m] != 1 || kLdsRowPos[m] >= kRows - 1 || used[kLdsRowPos[m]]++) abort(); }
         if (kLdsRowPos[kRows - 1] != kRows - 1) abort();
+        // The search can also move variable nodes between lanes (34 instead of 66 extra cycles); the kernel keeps variable n on lane
+        // n mod 64, slot n / 64 -- codeword order falls out of the ballots for free -- so the header must have been generated with
+        // --fixed-variables (DESIGN.md section 4 has the estimate that decided it).
+        for (int r = 0; r < 3; ++r)
+            for (int l = 0; l < 64; ++l)
+                if (kVarOf[r][l] != (l + 64 * r < kLdpcN ? l + 64 * r : 255)) abort();
     }
     for (int G = 1; G <= kMaxCheckGroups; ++G) {
         for (int g = 0; g < kMaxCheckGroups; ++g)
