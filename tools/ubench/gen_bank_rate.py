@@ -82,6 +82,16 @@ chained("v_mul_f32 d_i = d_(i+1) * b   (chained, not in place)", "v_mul_f32", Fa
 chained("v_pk_mul_f32 d_i = d_(i+1) * b   (chained, not in place)", "v_pk_mul_f32", True)
 chained("v_pk_add_f32 d_i = d_(i+1) + b   (chained, not in place)", "v_pk_add_f32", True)
 
+# which operand position makes the in-place form dearer?
+scalar("v_mul_f32 d,b,d   (dst == src1)", "v_mul_f32 {d}, {a}, {d}", (1, 0, 0))
+scalar("v_mul_f32_e64 d,d,b  (VOP3 encoding, dst == src0)", "v_mul_f32_e64 {d}, {d}, {a}", (1, 0, 0))
+scalar("v_mul_f32_e64 d,a,b  (VOP3 encoding, three-address)", "v_mul_f32_e64 {d}, {a}, {b}", (1, 2, 0))
+scalar("v_fma_f32 d,a,d,b  (dst == src1)", "v_fma_f32 {d}, {a}, {d}, {b}", (1, 2, 0))
+scalar("v_fma_f32 d,a,b,d  (dst == src2)", "v_fma_f32 {d}, {a}, {b}, {d}", (1, 2, 0))
+packed("v_pk_mul_f32 d,b,d  (dst == src1)", "v_pk_mul_f32 {d}, {a}, {d}", (1, 0, 0))
+packed("v_pk_fma_f32 d,a,b,d  (dst == src2)", "v_pk_fma_f32 {d}, {a}, {b}, {d}", (1, 0, 0))
+packed("v_pk_add_f32 d,a,b  three-address", "v_pk_add_f32 {d}, {a}, {b}", (1, 0, 0))
+
 src = ['// GENERATED by tools/ubench/gen_bank_rate.py -- do not edit', '#include <hip/hip_runtime.h>', '#include <stdio.h>',
        '#define N_ITERS 4096', f'#define CLOB {CLOB}', '']
 for k, (name, ins) in enumerate(variants):
