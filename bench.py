@@ -71,8 +71,8 @@ def csrc_hash():
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, choices=(1, 2, 3, 4), default=2, help="index into BASELINE.json configs (default 2: the metric's configuration)")
     ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default: the config's)")
     ap.add_argument("--nsig", type=int, default=None, help="FT8 signals per frame")
