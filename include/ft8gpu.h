@@ -117,7 +117,9 @@ int  ft8gpu_create(ft8gpu_ctx **out, int device, int max_frames, const ft8gpu_pa
 void ft8gpu_destroy(ft8gpu_ctx *ctx);
 /* Use an existing hipStream_t (passed as void*) for all work of this context.  NULL = the context
  * creates its own non-blocking stream; FT8GPU_STREAM_LEGACY (= hipStreamLegacy) selects the legacy
- * null stream explicitly. */
+ * null stream explicitly.  The call synchronises the old and the new stream and runs the co-execution probe of
+ * ft8gpu_overlap_active on the new one (a few one-thread kernels and host synchronisations, well under a millisecond
+ * when the streams co-run): do not call it on a stream that is being captured into a graph. */
 int  ft8gpu_set_stream(ft8gpu_ctx *ctx, void *hip_stream);
 #define FT8GPU_STREAM_LEGACY ((void *)1)
 /* The hipStream_t (as void*) the context enqueues on, so that a caller can order its own work behind the decoder's
