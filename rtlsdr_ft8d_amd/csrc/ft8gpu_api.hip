@@ -1086,10 +1086,14 @@ int ft8gpu_rx_decimate(ft8gpu_ctx *c, const uint8_t *raw, int ncaptures, size_t 
     if (!raw || !iq) return fail("NULL array argument");
     if (npairs % 8 != 0) return fail("npairs must be a multiple of 8 (whole 16-byte units; the reference's buffers are multiples of 8 bytes)");
     const size_t nblocks = npairs / 751 > (size_t)kNSamples ? (size_t)kNSamples : npairs / 751;
-    HIP_TRY(hipStreamSynchronize(c->stream));              // scratch may be regrown below
-    if (grow(&c->d_rx_sums, &c->rx_sums_cap, (size_t)ncaptures * (nblocks + 1) * 16)) return -1;
-    if (grow(&c->d_rx_p2, &c->rx_p2_cap, (size_t)ncaptures * ((nblocks + 15) / 16 + 1) * 16 + (size_t)ncaptures * 376 * 4)) return -1;
     const size_t raw_bytes = (size_t)ncaptures * npairs * 2, iq_bytes = (size_t)ncaptures * 2 * kNSamples * sizeof(float);
+    const size_t sums_bytes = (size_t)ncaptures * (nblocks + 1) * 16;
+    const size_t p2_bytes = (size_t)ncaptures * ((nblocks + 15) / 16 + 1) * 32 + (size_t)ncaptures * 376 * 4;   // entry states + group totals + partial peaks
+    const bool staged = !(flags & FT8GPU_DEVICE_PTRS);
+    if (sums_bytes > c->rx_sums_cap || p2_bytes > c->rx_p2_cap || (staged && (raw_bytes > c->rx_raw_cap || iq_bytes > c->rx_iq_cap)))
+        HIP_TRY(hipStreamSynchronize(c->stream));          // a buffer is regrown below: earlier launches may still use the old one
+    if (grow(&c->d_rx_sums, &c->rx_sums_cap, sums_bytes)) return -1;
+    if (grow(&c->d_rx_p2, &c->rx_p2_cap, p2_bytes)) return -1;
     if (flags & FT8GPU_DEVICE_PTRS) {
         if (((uintptr_t)raw & 15) != 0) return fail("raw must be 16-byte aligned");
         HIP_TRY(launch_rx(raw, ncaptures, npairs, c->d_rx_sums, c->d_rx_p2, iq, normalise, c->stream));
