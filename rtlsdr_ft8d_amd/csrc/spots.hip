@@ -24,19 +24,28 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 constexpr int kTextDw = 7;                    // message_t.text[25] in 7 aligned dwords (bytes 25..27 are 0)
 
-// strcmp(a, b) == 0 on two staged texts
-__device__ inline bool text_equal(const uint32_t *a, const uint32_t *b) {
-    uint32_t wa[kTextDw], wb[kTextDw];
+// Staged texts are kept in CANONICAL form: every byte behind the first NUL is zero (what strcmp never looks at), so
+// strcmp(a, b) == 0 is equality of the seven dwords -- a dozen instructions instead of a 25-step byte loop, and that
+// comparison runs once per (lane, kept message) and once per (lane, unique message of the chunk).  The LDPC kernel
+// writes its texts into zero-filled records, but collect_spots also takes caller-made records: canonicalising here
+// keeps the reference's semantics for any input.
+__device__ __forceinline__ void canonical_text(uint32_t (&w)[kTextDw]) {
+    bool open = true;                               // no terminator seen yet
 #pragma unroll
-    for (int i = 0; i < kTextDw; ++i) { wa[i] = a[i]; wb[i] = b[i]; }
-    bool equal = true, open = true;                 // open: no terminator seen yet
-#pragma unroll
-    for (int i = 0; i < 25; ++i) {
-        const uint32_t ca = (wa[i >> 2] >> (8 * (i & 3))) & 0xFFu, cb = (wb[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-        equal = equal && (!open || ca == cb);
-        open = open && ca != 0;
+    for (int k = 0; k < kTextDw; ++k) {
+        const uint32_t v = open ? w[k] : 0u;
+        const uint32_t z = ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;   // 0x80 in every zero byte (exact, no carries between bytes)
+        const uint32_t low = z & (0u - z);          // the first one: 0x80 << 8 i  (0 if none)
+        w[k] = v & ((low >> 7) - 1u);               // bytes below it (all four if none)
+        open = open && z == 0u;
     }
-    return equal;
+}
+// strcmp == 0 between the lane's own text (registers) and a staged one
+__device__ __forceinline__ bool text_equal(const uint32_t (&mine)[kTextDw], const uint32_t *other) {
+    uint32_t d = 0;
+#pragma unroll
+    for (int k = 0; k < kTextDw; ++k) d |= mine[k] ^ other[k];
+    return d == 0u;
 }
 
 // strtok(text, " ") semantics on message_t.text with text[24] taken as the terminator (:1509 works on a
@@ -94,45 +103,59 @@ void ft8_spots_kernel(const ft8gpu_candidate *__restrict__ cands, const int32_t 
     const ft8gpu_candidate *fc = cands + (size_t)frame * max_candidates;
     const ft8gpu_decode_status *fs = status + (size_t)frame * max_candidates;
     struct decoder_results *out = decodes + (size_t)frame * kMaxMessages;
-    const int num_candidates = counts[frame];
     const int words = (max_candidates + 63) / 64;
     const unsigned long long below = (1ull << lane) - 1ull;
+
+    // One chunk of 64 candidates per round; the candidate and the nine record dwords a lane needs are fetched a chunk
+    // AHEAD (and the first chunk together with the frame's candidate count: rows below max_candidates always exist),
+    // so the kernel waits for memory once, not four times in a row -- it is nothing but a chain of latencies.
+    struct Fetched { uint64_t cand; uint32_t hash_dw, st2, t[7]; };
+    auto fetch = [&](int w) {
+        Fetched f = {};
+        const int idx = w * 64 + lane;
+        if (idx < max_candidates) {
+            f.cand = reinterpret_cast<const uint64_t *>(fc)[idx];
+            const uint32_t *rec = reinterpret_cast<const uint32_t *>(fs + idx);                   // 48-byte record, 12 dwords
+            f.hash_dw = rec[1];                                                                   // crc_extracted | crc_calculated << 16
+            f.st2 = rec[2];                                                                       // unpack_status | ok << 8 | a91[0..1]
+#pragma unroll
+            for (int k = 0; k < 7; ++k) f.t[k] = rec[5 + k];                                      // bytes 20..47; text starts at byte 22
+        }
+        return f;
+    };
+    Fetched nxt = fetch(0);
+    const int num_candidates = counts[frame];
 
     int num_decoded = 0;                                                      // wave-uniform
     for (int w = 0; w < words; ++w) {                                         // :1465, candidate order
         const int idx = w * 64 + lane;
-        bool ok = false;
-        uint64_t cand_bits = 0;
+        const Fetched cur = nxt;
+        if (w + 1 < words) nxt = fetch(w + 1);
+        const uint64_t cand_bits = cur.cand;
+        const bool ok = idx < num_candidates && (int16_t)(cand_bits & 0xFFFFu) >= min_score && ((cur.st2 >> 8) & 0xFFu) != 0;   // :1467, :1476-1485
         uint32_t my_hash = 0;
-        if (idx < num_candidates) {
-            cand_bits = reinterpret_cast<const uint64_t *>(fc)[idx];
-            const uint32_t st2 = reinterpret_cast<const uint32_t *>(fs + idx)[2];                 // unpack_status | ok << 8 | a91[0..1]
-            ok = (int16_t)(cand_bits & 0xFFFFu) >= min_score && ((st2 >> 8) & 0xFFu) != 0;        // :1467, :1476-1485
-        }
+        uint32_t mine[kTextDw] = {};                                          // the lane's text, canonical
         const unsigned long long live = __ballot(ok);
         if (live == 0ull) continue;                                           // wave-uniform
         if (ok) {
-            const uint32_t *rec = reinterpret_cast<const uint32_t *>(fs + idx);                   // 48-byte record, 12 dwords
-            my_hash = rec[1] & 0xFFFFu;                                                           // crc_extracted = message.hash
+            my_hash = cur.hash_dw & 0xFFFFu;                                                      // crc_extracted = message.hash
             L.chash[lane] = (uint16_t)my_hash;
             L.ccand[lane] = cand_bits;
-            uint32_t r[8];
-#pragma unroll
-            for (int k = 0; k < 7; ++k) r[k] = rec[5 + k];                    // bytes 20..47; text starts at byte 22
-            r[7] = 0;
 #pragma unroll
             for (int k = 0; k < kTextDw; ++k) {
-                uint32_t v = (r[k] >> 16) | (r[k + 1] << 16);
-                if (k == kTextDw - 1) v &= 0xFFu;                             // text[24] only (byte 47 is the record's pad)
-                L.ctext[lane][k] = v;
+                mine[k] = (cur.t[k] >> 16) | ((k + 1 < 7 ? cur.t[k + 1] : 0u) << 16);
+                if (k == kTextDw - 1) mine[k] &= 0xFFu;                       // text[24] only (byte 47 is the record's pad)
             }
+            canonical_text(mine);
+#pragma unroll
+            for (int k = 0; k < kTextDw; ++k) L.ctext[lane][k] = mine[k];
         }
         wave_lds_sync();
 
         // :1487-1503 -- is the message already known?  First against the messages kept from earlier chunks.
         bool dup = false;
         for (int t = 0; t < num_decoded; ++t)
-            if (ok && L.thash[t] == my_hash && text_equal(L.ttext[t], L.ctext[lane])) dup = true;
+            if (ok && L.thash[t] == my_hash && text_equal(mine, L.ttext[t])) dup = true;
         // Then inside the chunk, leader by leader: the first lane that is still undecided cannot have an equal
         // message before it (that one would be a leader, and would have struck it), so it is NEW; it strikes every
         // later lane carrying its message.  One round per UNIQUE message of the chunk (about a dozen) instead of
@@ -141,7 +164,7 @@ void ft8_spots_kernel(const ft8gpu_candidate *__restrict__ cands, const int32_t 
         while (pending != 0ull) {                                             // wave-uniform
             const int j = __builtin_ctzll(pending);
             fresh |= 1ull << j;
-            const bool same = ok && !dup && lane > j && L.chash[j] == my_hash && text_equal(L.ctext[j], L.ctext[lane]);
+            const bool same = ok && !dup && lane > j && L.chash[j] == my_hash && text_equal(mine, L.ctext[j]);
             dup = dup || same;
             pending &= ~((1ull << j) | __ballot(same));
         }
@@ -149,7 +172,7 @@ void ft8_spots_kernel(const ft8gpu_candidate *__restrict__ cands, const int32_t 
         const bool keep = ((fresh >> lane) & 1ull) != 0ull && rank < kMaxMessages;                  // table full: drop (the reference never terminates there)
         if (keep) {                                                           // :1505-1520
 #pragma unroll
-            for (int k = 0; k < kTextDw; ++k) L.ttext[rank][k] = L.ctext[lane][k];
+            for (int k = 0; k < kTextDw; ++k) L.ttext[rank][k] = mine[k];
             L.thash[rank] = (uint16_t)my_hash;
             const char *text = reinterpret_cast<const char *>(L.ctext[lane]);
             int pos = 0, len = 0;
