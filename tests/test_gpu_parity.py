@@ -355,13 +355,14 @@ def test_selftest_through_dropin_symbol(oracle):
 
 
 def test_collect_spots_dedup_and_table_full(oracle, gpu_decoder):
-    """>50 unique messages (the reference's non-terminating case), duplicates, non-CQ, 2-token CQ"""
+    """>50 unique messages (the reference's non-terminating case), duplicates, non-CQ, 2-token CQ, and caller-made
+    records with bytes behind the text's terminator (strcmp never looks at them; the kernel compares canonical dwords)"""
     import rtlsdr_ft8d_amd as ft8
     rng = np.random.default_rng(3)
     C = 120
-    cands = np.zeros((2, C), ft8.CAND_DTYPE)
-    st = np.zeros((2, C), ft8.STATUS_DTYPE)
-    counts = np.array([C, 12], np.int32)
+    cands = np.zeros((3, C), ft8.CAND_DTYPE)
+    st = np.zeros((3, C), ft8.STATUS_DTYPE)
+    counts = np.array([C, 12, 8], np.int32)
     for c in range(C):
         cands[0, c] = (100 - c // 2, 0, c, 0, c & 1)
         st[0, c]["ok"] = 1
@@ -375,9 +376,17 @@ def test_collect_spots_dedup_and_table_full(oracle, gpu_decoder):
         st[1, c]["crc_extracted"] = 77 if c < 3 else 100 + c
         st[1, c]["text"] = t
     cands[1, 10]["score"] = 5          # below min_score -> skipped at :1467
+    dirty = [b"CQ K1ABC FN42\0XYZ", b"CQ K1ABC FN42\0QQQQQQQQQQQ", b"CQ K1ABC FN42", b"CQ K1ABC FN4\0" + b"2", b"CQ K1ABC FN4\0Z",
+             b"\0CQ K9ZZZ EM10", b"\0\0\0\0junk", b"CQ W1AW FN31\0\0\0\0\0\0\0\0\0\0\0\0x"]
+    for c, t in enumerate(dirty):
+        cands[2, c] = (40 - c, 0, 30 + c, 0, c & 1)
+        st[2, c]["ok"] = 1
+        st[2, c]["crc_extracted"] = 4242 if c < 7 else 4243
+        raw = np.frombuffer(t.ljust(25, b"\0"), np.uint8)
+        st.view(np.uint8).reshape(3, C, 48)[2, c, 22:47] = raw      # the text field, byte for byte (embedded NULs kept)
     dec, n = gpu_decoder.collect_spots(cands, counts, st)
     # reference semantics restated directly in Python for this synthetic table
-    for f in range(2):
+    for f in range(3):
         table = [None] * 50
         out = np.zeros(50, ft8.RESULT_DTYPE)
         nd = 0
@@ -385,7 +394,7 @@ def test_collect_spots_dedup_and_table_full(oracle, gpu_decoder):
             if cands[f, c]["score"] < 10 or not st[f, c]["ok"]:
                 continue
             h = int(st[f, c]["crc_extracted"])
-            text = bytes(st[f, c]["text"]).split(b"\0")[0]
+            text = st.view(np.uint8).reshape(3, C, 48)[f, c, 22:47].tobytes().split(b"\0")[0]
             idx, probes, empty, dup = h % 50, 0, False, False
             while True:
                 if table[idx] is None:

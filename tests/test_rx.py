@@ -69,7 +69,8 @@ def test_oracle_rx_chain_properties(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,npairs", [("signal", 751 * 3000 + 8 * 37), ("random", 751 * 2000), ("extremes", 751 * 1500 + 744),
-                                         ("zeros", 751 * 100), ("signal", 8 * 50), ("random", 751 * 48000 + 8 * 1000)])
+                                         ("zeros", 751 * 100), ("signal", 8 * 50), ("random", 751 * 48000 + 8 * 1000),
+                                         ("random", 752), ("extremes", 751 * 17 + 1), ("random", 751 * 16)])   # 1, 17 and 16 blocks: one partial group, a full one plus one block, exactly one
 def test_gpu_rx_bit_exact(oracle, gpu_decoder, kind, npairs):
     npairs -= npairs % 8
     raws = np.stack([make_capture(10 + k, npairs, kind) for k in range(2)])
