@@ -109,7 +109,7 @@ struct ft8gpu_ctx {
     hipStream_t side = nullptr;            // carries the serial kernels (heap, spots) of one half-batch
                                            // while the main stream works on the other half
     hipStream_t side2 = nullptr;           // heap replay of part B (beside the one of part A on `side`)
-    hipEvent_t dep[6]{};                   // cross-stream dependencies (no timing)
+    hipEvent_t dep[4]{};                   // cross-stream dependencies (no timing)
     bool overlap_ok = false;               // main, side and side2 were SEEN to run kernels concurrently (probe_streams)
     int *d_probe = nullptr;                // two ints for that probe
     char overlap_why[160] = "";            // why the overlapped pipeline is off (empty when it is on)
@@ -275,14 +275,13 @@ int probe_streams(ft8gpu_ctx *c) {
     return 0;
 }
 
-// Large batches: the two serial kernels (exact heap replay, spot collection) keep only one lane per frame
-// busy, so the batch is cut into a first part A (a quarter) and the rest B, and their serial kernels run on side
-// streams under the throughput kernels of the other part:
-//   main : wf(A) sync(A) wf(B) sync(B) ..wait heap(A).. decode(A) ..wait heap(B).. decode(B) spots(B)
-//   side :            heap(A)                                          spots(A)
+// Large batches: the exact heap replay is a serial kernel (a lane or a wave per frame), so the batch is cut into a first
+// part A (a quarter) and the rest B, and the replays run on side streams under the throughput kernels of the other part:
+//   main : wf(A) sync(A) wf(B) sync(B) ..wait heap(A).. decode(A) ..wait heap(B).. decode(B) spots(A+B)
+//   side :            heap(A)
 //   side2:                        heap(B)
-// heap(A) hides under the waterfall and sync kernels of B, heap(B) under decode(A), spots(A) under decode(B); what
-// stays exposed is spots(B) and one extra LDPC-kernel tail.  The heap replay is a dependent chain whose length grows
+// heap(A) hides under the waterfall and sync kernels of B, heap(B) under decode(A); what stays exposed is the spot
+// collection (27 us) and one extra LDPC-kernel tail.  The heap replay is a dependent chain whose length grows
 // with the candidate cap (about 0.1 ms at 120, 0.35 ms at 480) and hardly with the number of frames, so at large caps
 // part A is made big enough for decode(A) to cover heap(B).  (Round 2 ran ONE waterfall launch up front, which left
 // heap(A) only sync(B) to hide under.  Measured alternatives, profiles/r02_ab_kernels.json and r03_ab_pipeline.json:
@@ -310,10 +309,10 @@ int run_pipeline_overlapped(ft8gpu_ctx *c, const float *d_iq, int n, struct deco
     ft8gpu_candidate *cands1 = c->d_cands + lo * mc;
     int32_t *counts1 = c->d_counts + lo;
     ft8gpu_decode_status *st1 = c->d_status + lo * mc;
-    hipEvent_t *E = c->dep;          // 0: sync(A) done  1: sync(B) done  2: heap(A)  3: heap(B)  4: decode(A)  5: side stream done
+    hipEvent_t *E = c->dep;          // 0: sync(A) done  1: sync(B) done  2: heap(A)  3: heap(B)
 
-    // main stream events: 0 wf(A) 1 sync(A) 2 wf(B) 9 sync(B) 3 | 4 decode(A) 5 decode(B) 6 spots(B) 7 | 8 end
-    // side stream events: 0 heap(A) 1 | 4 spots(A) 5        side2: 2 heap(B) 3
+    // main stream events: 0 wf(A) 1 sync(A) 2 wf(B) 9 sync(B) 3 | 4 decode(A) 5 decode(B) 6 spots 7 | 8 end
+    // side stream events: 0 heap(A) 1        side2: 2 heap(B) 3
     t.mark(0);
     HIP_TRY(launch_waterfall(d_iq, c->d_mag, c->d_tab, n0, c->num_cus, c->debug_flags, c->stream));
     t.mark(1);
@@ -342,24 +341,19 @@ int run_pipeline_overlapped(ft8gpu_ctx *c, const float *d_iq, int n, struct deco
     HIP_TRY(launch_heap(lists1, lc1, cands1, counts1, n1, mc, c->debug_flags, c->side2, hide));
     t.mark_on(c->side2, 3);
     HIP_TRY(hipEventRecord(E[3], c->side2));
-    // main stream: decode(A), decode(B), spots(B)
+    // main stream: decode(A), decode(B), spots
     HIP_TRY(hipStreamWaitEvent(c->stream, E[2], 0));
     t.mark(4);
     HIP_TRY(launch_decode(c->d_mag, c->d_cands, c->d_counts, c->d_status, n0, mc, p.ldpc_iters, false, force_ieee(c), c->stream));
     t.mark(5);
-    HIP_TRY(hipEventRecord(E[4], c->stream));
     HIP_TRY(hipStreamWaitEvent(c->stream, E[3], 0));
     HIP_TRY(launch_decode(mag1, cands1, counts1, st1, n1, mc, p.ldpc_iters, false, force_ieee(c), c->stream));
     t.mark(6);
-    // side stream: spots(A) while decode(B) runs
-    HIP_TRY(hipStreamWaitEvent(c->side, E[4], 0));
-    t.mark_side(4);
-    HIP_TRY(launch_spots(c->d_cands, c->d_counts, c->d_status, n0, mc, p.min_score, d_dec, d_nres, c->side));
-    t.mark_side(5);
-    HIP_TRY(hipEventRecord(E[5], c->side));
-    HIP_TRY(launch_spots(cands1, counts1, st1, n1, mc, p.min_score, d_dec + lo * kMaxMessages, d_nres + lo, c->stream));
+    // ONE spot collection for both parts behind the last LDPC launch (the parts' buffers are contiguous).  Until round 4 the
+    // spots of part A ran on the side stream beside decode(B); since the kernel takes 27 us for 4096 frames that bought
+    // nothing and cost two event hops on the main stream: 4.115 -> 4.077 ms per step in interleaved A/B.
+    HIP_TRY(launch_spots(c->d_cands, c->d_counts, c->d_status, n, mc, p.min_score, d_dec, d_nres, c->stream));
     t.mark(7);
-    HIP_TRY(hipStreamWaitEvent(c->stream, E[5], 0));
     t.mark(8);
     t.done(1);
     return 0;
@@ -571,13 +565,12 @@ int ft8gpu_get_timings(ft8gpu_ctx *c, ft8gpu_timings *out, int32_t *nruns) {
         hipEvent_t *e = c->ev[slot];
         if (c->slot_form[slot] != 0) {
             hipEvent_t *sd = e + ft8gpu_ctx::kSideEv0;
-            HIP_TRY(hipEventSynchronize(e[8]));
-            HIP_TRY(hipEventSynchronize(sd[5]));
+            HIP_TRY(hipEventSynchronize(e[8]));               // (the main stream has waited for both side streams by then)
             acc[0] += elapsed(e[0], e[1]) + elapsed(e[2], e[9]);             // waterfall: both parts
             acc[1] += elapsed(e[1], e[2]) + elapsed(e[9], e[3]);             // sync: both parts
             acc[2] += elapsed(sd[0], sd[1]) + elapsed(sd[2], sd[3]);         // heap: both parts (side stream, overlapped)
             acc[3] += elapsed(e[4], e[5]) + elapsed(e[5], e[6]);             // decode: both launches
-            acc[4] += elapsed(sd[4], sd[5]) + elapsed(e[6], e[7]);           // spots: A (side, overlapped) + B
+            acc[4] += elapsed(e[6], e[7]);                                   // spots: both parts in one launch
             acc[5] += elapsed(e[0], e[8]);
             launches = 2;
         } else {

@@ -78,11 +78,10 @@ __device__ inline void put_field(char *dst, int cap, int prec, const char *tok, 
     dst[n] = 0;
 }
 
-// LDS per wave: staged texts [64][7 dw], candidates [64] and hashes [64] of the current chunk; texts
-// and hashes of the messages kept so far [50]
+// LDS per wave: staged texts [64][7 dw] and hashes [64] of the current chunk; texts and hashes of the
+// messages kept so far [50]
 struct SpotsWaveLds {
     uint32_t ctext[64][kTextDw];
-    uint64_t ccand[64];
     uint32_t ttext[kMaxMessages][kTextDw];
     uint16_t chash[64];
     uint16_t thash[kMaxMessages];
@@ -140,7 +139,6 @@ void ft8_spots_kernel(const ft8gpu_candidate *__restrict__ cands, const int32_t 
         if (ok) {
             my_hash = cur.hash_dw & 0xFFFFu;                                                      // crc_extracted = message.hash
             L.chash[lane] = (uint16_t)my_hash;
-            L.ccand[lane] = cand_bits;
 #pragma unroll
             for (int k = 0; k < kTextDw; ++k) {
                 mine[k] = (cur.t[k] >> 16) | ((k + 1 < 7 ? cur.t[k + 1] : 0u) << 16);
