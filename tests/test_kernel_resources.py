@@ -30,3 +30,24 @@ def test_no_kernel_uses_scratch_and_no_dpp_follows_a_cmpx(tmp_path):
     assert ks["ft8_decode_kernel<false, 3>"]["sgprs"] <= 80          # 256-thread workgroups: 8 per CU only up to 80 SGPRs
     # four waves of at most 120 registers leave 32 per lane free: the heap replay's waves run beside the waterfall kernel
     assert ks["ft8_waterfall_kernel<0>"]["vgprs"] <= 120 and ks["ft8_waterfall_kernel<0>"]["waves_per_simd_by_vgprs"] == 4
+
+
+def test_committed_counter_evidence_describes_these_kernel_sources():
+    """profiles/pmc_traffic.json carries the hash of csrc/ it was collected on; bench.py reports the counter-derived roofline
+    figures (traffic, valu_*) only while that hash matches the tree.  A mismatch is not an error of the code -- it means
+    tools/gpu_round.sh has to run again on a GPU box -- so it is reported as a SKIP with the reason, not as a failure."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    with open(os.path.join(root, "profiles", "pmc_traffic.json")) as f:
+        t = json.load(f)
+    assert isinstance(t.get("csrc_sha"), str) and len(t["csrc_sha"]) == 16
+    for kernel in ("waterfall", "sync", "heap", "decode", "spots"):
+        assert t[kernel]["hbm_bytes_per_frame"] > 0 and 0.0 < t[kernel]["valu_busy_frac"] <= 1.0
+    if t["csrc_sha"] != bench.csrc_hash():
+        import pytest
+        pytest.skip(f"profiles/pmc_traffic.json was collected on csrc {t['csrc_sha']}, the tree is {bench.csrc_hash()}: "
+                    "re-run TAG=rNN bash tools/gpu_round.sh on a GPU box and copy gpurun_out/profiles_rNN/* to profiles/")
