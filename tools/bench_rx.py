@@ -47,7 +47,14 @@ def main():
            "captures_per_s": round(args.captures / ms * 1e3, 1),
            "roofline": {"bound": "hbm", "achieved": round((bytes_in + bytes_out) / ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
                         "frac": round((bytes_in + bytes_out) / ms / 1e6 / 8000.0, 4),
-                        "algorithmic_bytes_per_launch": bytes_in + bytes_out}}
+                        "algorithmic_bytes_per_launch": bytes_in + bytes_out, "traffic": None}}
+    try:        # HBM bytes of the block kernel from the committed counter passes (16 captures per launch), scaled to this launch
+        with open(os.path.join(ROOT, "profiles", "r04_rx_pmc_traffic.json")) as f:
+            pm = json.load(f)["block_kernel"]
+        out["roofline"]["traffic"] = int((pm["fetch_bytes_per_launch_corrected"] + pm["write_bytes_per_launch_raw"]) * args.captures / 16)
+        out["roofline"]["traffic_from"] = "profiles/r04_rx_pmc_traffic.json (block kernel: FETCH_SIZE x 2 + WRITE_SIZE, per 16 captures)"
+    except (OSError, KeyError, ValueError):
+        pass
     if args.cpu_captures > 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
