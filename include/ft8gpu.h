@@ -100,8 +100,9 @@ typedef struct {
     float spots_ms;       /* dedup + CQ spot fill */
     float total_ms;       /* first kernel start to last kernel end */
     int32_t launches_per_stage; /* 1, or 2 when a large batch is processed as two overlapped parts (the first quarter and the
-                                   rest): heap and spots of one part then run on side streams under the other part's kernels,
-                                   and the per-stage figures are sums over both launches of every stage */
+                                   rest): the heap replay of one part then runs on a side stream under the other part's
+                                   kernels, and the per-stage figures are sums over both launches of a stage (the spot
+                                   collection is one launch for both parts) */
 } ft8gpu_timings;
 
 /* ---- lifecycle: replaces initFFTW()/freeFFTW(), rtlsdr_ft8d.c:314-347 ----------------------- */
