@@ -24,7 +24,6 @@ the host cores.  The host half has no product implementation (the product decode
 CPU oracle, i.e. this mode measures "GPU front end + reference-style CPU back end", and says so in its line.
 """
 import argparse
-import hashlib
 import json
 import os
 import sys
@@ -58,14 +57,10 @@ CONFIGS = {
 
 
 def csrc_hash():
-    """identity of the kernel sources the committed PMC summaries were collected on"""
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "rtlsdr_ft8d_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")):          # device code and its headers (host-only .c files do not change a kernel)
-            with open(os.path.join(d, name), "rb") as f:
-                h.update(name.encode() + b"\0" + f.read())
-    return h.hexdigest()[:16]
+    """identity of the kernel sources the committed PMC summaries were collected on: the device half of the library's
+    build id (csrc/*.hip, *.h; host-only .c files do not change a kernel)"""
+    import rtlsdr_ft8d_amd as ft8
+    return ft8.device_source_id()
 
 
 def parse_args(argv=None):
@@ -302,6 +297,10 @@ def main():
     # streams on three different queues.  (Created after RCCL's and torch's streams, the main and one side stream landed
     # on the same queue and the heap replay of part A no longer ran beside the waterfall of part B: +0.27 ms per step,
     # tools/trace_gaps.py on a rocprofv3 kernel trace.)
+    # a stale or foreign libft8gpu.so fails here instead of producing numbers: the id baked into the library at link time must
+    # be the one the sources beside it hash to
+    out["build_id"] = ft8.check_build_id()
+
     def make_decoder():
         d = ft8.Decoder(device=local_rank, max_frames=B, min_score=10, max_candidates=maxc, ldpc_iters=20)
         if args.debug_flags:
@@ -309,6 +308,8 @@ def main():
             out["debug_flags"] = args.debug_flags           # not the product configuration
         # the context has measured whether its streams co-run (ft8gpu_overlap_active): the two-part pipeline or the plain one
         out["overlap"] = d.overlap_active()
+        if not out["overlap"]:
+            out["overlap_reason"] = d.overlap_reason()
         return d
 
     dec = None
@@ -706,6 +707,7 @@ def host_legs(dec, iq, spots, nres, B):
     out["host_fed_frames_per_s"] = round(m / dt, 1)
     out["host_fed"] = {"frames": m, "ms": round(1e3 * dt, 2), "upload_GBps": round(m * 384000 / dt / 1e9, 1), "records_identical_to_hbm_resident_run": same,
                        "host_memory": "ft8gpu_host_alloc (page-locked)"}
+    del h                                                                # no view may outlive the allocation (PinnedArray.close refuses)
     pinned.close()
     ncap, npairs = 4, 36_000_000                                         # 15 s at 2.4 Msps
     raw = torch.randint(0, 256, (ncap, 2 * npairs), dtype=torch.uint8, generator=torch.Generator().manual_seed(3)).pin_memory().numpy()

@@ -6,8 +6,9 @@
 extern "C" {
 #endif
 #pragma GCC visibility push(default)
-/* "CALL1 CALL2 [GRID4]" standard (i3 = 1) messages -> 77 bits in c77[0..9] (c77 must hold FTX_LDPC_K_BYTES);
- * returns 0, or -1 if the text is not such a message (other message types are not needed on this path) */
+/* message text -> 77 bits in c77[0..9] (c77 must hold FTX_LDPC_K_BYTES); returns 0, or -1 if the text fits no message
+ * type.  Everything ft8_lib's pack77 packs (standard calls with grid / report / RRR / RR73 / 73, else free text) and
+ * more: see ft8gpu_pack77 in ft8gpu.h */
 int pack77(const char *msg, uint8_t *c77);
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -11,8 +11,8 @@
  *   waterfall = uint8 mag[92][2][2][256] (block, time_sub, freq_sub, bin) = 94208 bytes per frame.
  *
  * Environment: FT8GPU_DEVICE=<n> is the GPU used by the drop-in ft8_subsystem (default 0; the reference's function has no
- * device argument).  Nothing else is read from the environment: every test hook and every alternative kernel form is a
- * per-context flag (ft8gpu_set_debug_flags), so that behaviour never depends on the process environment.
+ * device argument).  Nothing else is read from the environment: every test hook is a per-context flag
+ * (ft8gpu_set_debug_flags), so that behaviour never depends on the process environment.
  */
 #ifndef FT8GPU_H
 #define FT8GPU_H
@@ -130,24 +130,30 @@ int  ft8gpu_set_stream(ft8gpu_ctx *ctx, void *hip_stream);
  * on the context's own at 1024 frames, cap 480). */
 void *ft8gpu_get_stream(ft8gpu_ctx *ctx);
 /* 1: batches of >= 512 frames run the two-part pipeline with the serial kernels (heap replay, spot collection) on side
- * streams under the throughput kernels of the other part; 0: plain pipeline, one launch per stage (ft8gpu_last_error()
- * then says why).  Whether streams run side by side depends on which hardware queues HIP hands out, so the context
- * measures it at ft8gpu_create and again at ft8gpu_set_stream (a 2 ms co-execution probe per pair of streams), replaces
- * side streams that share a queue with another one, and only falls back when that does not help.  Records are identical
- * either way. */
+ * streams under the throughput kernels of the other part; 0: plain pipeline, one launch per stage.  Whether streams run
+ * side by side depends on which hardware queues HIP hands out, so the context measures it at ft8gpu_create and again at
+ * ft8gpu_set_stream (a 2 ms co-execution probe per pair of streams), replaces side streams that share a queue with another
+ * one, and only falls back when that does not help.  Records are identical either way.  A pure query: it does not touch
+ * ft8gpu_last_error().  The probe is a timing measurement: on a GPU shared with other work, or under a profiler that
+ * serialises kernels, it can come out 0 -- ft8gpu_overlap_reason says why. */
 int  ft8gpu_overlap_active(ft8gpu_ctx *ctx);
+/* why the plain pipeline runs ("" while the overlapped one is active), copied into buf (NUL-terminated, truncated to cap) */
+int  ft8gpu_overlap_reason(ft8gpu_ctx *ctx, char *buf, size_t cap);
 /* test hooks, per context (any combination; 0 = product behaviour) */
 #define FT8GPU_DBG_FORCE_IEEE_DIV 1u  /* LDPC kernel: the compiler's IEEE division everywhere (the guard's fallback path) */
 #define FT8GPU_DBG_PIPELINE_FORM  2u  /* ft8gpu_decode_candidates runs the form of the LDPC kernel ft8gpu_decode_batch
                                          uses (no exact error count: ldpc_errors is 0 or 83) */
 #define FT8GPU_DBG_NO_OVERLAP     4u  /* one launch per stage for the whole batch: no two-half overlap, no chunked upload */
-/* alternative, bit-identical forms of kernels (the product form is the one with no bit set; DESIGN.md section 4 has
- * the measurements that picked it).  The two heap bits exclude each other. */
-#define FT8GPU_DBG_WATERFALL_LDS  8u  /* last FFT stage: second exchange through LDS instead of register transposes across the wave's rows */
-#define FT8GPU_DBG_HEAP_LANE_PER_FRAME 16u  /* heap replay: one lane per frame for every launch the cap allows (<= 128) */
-#define FT8GPU_DBG_HEAP_WAVE_PER_FRAME 32u  /* heap replay: one wave per frame for every launch */
-#define FT8GPU_DBG_ALL            63u
-int  ft8gpu_set_debug_flags(ft8gpu_ctx *ctx, unsigned flags);   /* unknown bits and excluded pairs are refused */
+#define FT8GPU_DBG_ALL            7u
+/* (Alternative, bit-identical forms of the waterfall and heap kernels are not in this library: they are compiled into the
+ * A/B build only -- `make -C rtlsdr_ft8d_amd/csrc ab` -> libft8gpu_ab.so, whose ft8gpu_set_debug_flags accepts the extra
+ * selector bits of csrc/ft8gpu_internal.h.) */
+int  ft8gpu_set_debug_flags(ft8gpu_ctx *ctx, unsigned flags);   /* unknown bits are refused */
+/* Identity of the build: "<dev>.<all>[+ab]" -- 16 hex digits of SHA-256 over the device sources (csrc/ *.hip, *.h) and 16 over
+ * every source of the library (those + csrc/ *.c, Makefile, include/), computed by the Makefile when the library is
+ * linked.  rtlsdr_ft8d_amd.source_build_id() recomputes it from the tree: smoke(), the GPU tests and bench.py refuse a
+ * library whose id differs from the sources beside it (a stale or foreign .so fails instead of producing numbers). */
+const char *ft8gpu_build_id(void);
 /* Proof by exhaustion behind the LDPC kernel's short division chains (csrc/bp_math.h): fast_tanh / fast_atanh of
  * ft8_lib ldpc.c (reached through ft8_decode, rtlsdr_ft8d.c:1476) are functions of one float, so all 2^32 inputs are
  * evaluated on the GPU, fast form against the compiler's IEEE-754 division, on the domain the kernel's guard
@@ -225,7 +231,20 @@ int ft8gpu_collect_spots(ft8gpu_ctx *ctx, const ft8gpu_candidate *cands, const i
 
 /* ---- tooling: encoder + synthetic frames (pack77 / ft8_encode / CPFSK synth of
  *      decoderSelfTest, rtlsdr_ft8d.c:924-955) --------------------------------------------- */
-/* "CALL1 CALL2 GRID4" standard (type 1) message -> 77 bits in 10 bytes (pack77, :927). 0 = ok */
+/* Message text -> 77 bits in 10 bytes (pack77, :927); 0 = ok, -1 = the text fits no message type.  Tokens are separated
+ * by blanks.  Tried in this order:
+ *   telemetry   one token of 18 hexadecimal digits (the first 0..7)                                       i3.n3 = 0.5
+ *   type 1 / 2  FIELD1 CALL2 [GRID4 | R GRID4 | +NN | -NN | R+NN | R-NN | RRR | RR73 | 73]                  i3 = 1 / 2
+ *               FIELD1 = CQ | CQ nnn | CQ aaaa | DE | QRZ | call; a call is a standard call sign, optionally with
+ *               /R (type 1) or /P (type 2), or <CALL> (sent as a 22-bit hash: receivers without a hash table -- the
+ *               reference's ft8_lib era -- print "<...>"); reports -30 .. +99
+ *   type 4      <CALL> LONGCALL [RRR | RR73 | 73]  |  LONGCALL <CALL> [...]  |  CQ LONGCALL                    i3 = 4
+ *               LONGCALL: up to 11 characters of [0-9A-Z/], sent in full; the bracketed call as a 12-bit hash
+ *   free text   up to 13 characters of [ 0-9A-Z+-./?]                                                   i3.n3 = 0.0
+ * (ft8_lib's pack77 of the reference's era packs the type 1 forms without suffixes, brackets, "R GRID4" and CQ
+ * modifiers, and turns everything else into free text.) */
+int  ft8gpu_pack77(const char *msg, uint8_t payload[10]);
+/* the strict subset of it: "CALL1 CALL2 [GRID4]" with plain standard calls (CQ / DE / QRZ allowed first), else -1 */
 int  ft8gpu_pack77_std(const char *msg, uint8_t payload[10]);
 /* payload -> 79 tone numbers (ft8_encode, :934) */
 void ft8gpu_encode(const uint8_t payload[10], uint8_t tones[FT8GPU_NN]);

@@ -5,12 +5,15 @@ gfx950 + C host side).  This module only binds it with ctypes for the tests and 
 there is no Python or CPU fallback: if the library is missing, import of the binding raises.
 """
 import ctypes as C
+import glob
+import hashlib
 import os
 
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libft8gpu.so")
+AB_LIB_PATH = os.path.join(_HERE, "libft8gpu_ab.so")      # `make -C csrc ab`: product kernels + the alternative kernel forms
 
 NSAMPLES = 48000            # rtlsdr_ft8d.h:34-35
 MAG_ARRAY = 94208           # rtlsdr_ft8d.h:56
@@ -50,7 +53,8 @@ class ReportInfo(C.Structure):
 DATAGRAM_STRIDE = 1408
 STREAM_LEGACY = 1                       # FT8GPU_STREAM_LEGACY (= hipStreamLegacy): the legacy null stream, explicitly
 DBG_FORCE_IEEE_DIV, DBG_PIPELINE_FORM, DBG_NO_OVERLAP = 1, 2, 4      # FT8GPU_DBG_* test hooks (per context)
-DBG_WATERFALL_LDS, DBG_HEAP_LANE_PER_FRAME, DBG_HEAP_WAVE_PER_FRAME = 8, 16, 32   # other (bit-identical) kernel forms
+# selector bits of the alternative (bit-identical) kernel forms: accepted by the A/B build only (csrc/ft8gpu_internal.h)
+AB_WATERFALL_LDS, AB_HEAP_LANE_PER_FRAME, AB_HEAP_WAVE_PER_FRAME = 8, 16, 32
 
 
 class Ft8GpuError(RuntimeError):
@@ -64,7 +68,7 @@ ABI_SYMBOLS = [
     "ft8gpu_decode_candidates", "ft8gpu_collect_spots", "ft8gpu_pack77_std", "ft8gpu_encode",
     "ft8gpu_synth_frames", "ft8gpu_synth_frames_at", "ft8gpu_rx_decimate", "ft8gpu_pskreporter_datagrams", "ft8gpu_format_spots",
     "ft8gpu_dev_alloc", "ft8gpu_dev_free", "ft8gpu_memcpy_h2d", "ft8gpu_memcpy_d2h", "ft8gpu_host_alloc", "ft8gpu_host_free",
-    "ft8gpu_overlap_active",
+    "ft8gpu_overlap_active", "ft8gpu_overlap_reason", "ft8gpu_build_id", "ft8gpu_pack77",
     "ft8gpu_set_debug_flags", "ft8gpu_selftest_bp_math", "ft8gpu_gather_spots", "ft8gpu_gather_shutdown",
     "ft8gpu_shard_workers", "ft8gpu_decode_batch_multi", "ft8gpu_decode_batch_multi_dev",
     "ft8_find_sync", "ft8_decode", "ft8_encode", "pack77",            # ft8_lib level (include/ft8_lib/ft8/*.h)
@@ -72,6 +76,43 @@ ABI_SYMBOLS = [
 ]
 
 _lib = None
+
+
+def _hash16(paths):
+    h = hashlib.sha256()
+    for path in paths:
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def source_build_id():
+    """what ft8gpu_build_id() of a library built from THIS tree returns (csrc/Makefile computes the same two hashes):
+    "<dev>.<all>" -- device sources (csrc/*.hip, *.h), and every source of the library (+ csrc/*.c, Makefile, include/)"""
+    d = os.path.join(_HERE, "csrc")
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    dev = sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")), key=os.path.basename)
+    rest = sorted(glob.glob(os.path.join(d, "*.c")), key=os.path.basename) + [os.path.join(d, "Makefile"), os.path.join(inc, "ft8gpu.h")] + \
+        sorted(glob.glob(os.path.join(inc, "ft8_lib", "ft8", "*.h")), key=os.path.basename)
+    return f"{_hash16(dev)}.{_hash16(dev + rest)}"
+
+
+def device_source_id():
+    """the first half of the build id: identity of the kernel sources (what committed PMC summaries are gated on)"""
+    return source_build_id().split(".")[0]
+
+
+def build_id(lib=None):
+    return (lib or load_library()).ft8gpu_build_id().decode()
+
+
+def check_build_id(lib=None, suffix=""):
+    """raises unless the loaded library was built from the sources beside it"""
+    have, want = build_id(lib), source_build_id() + suffix
+    if have != want:
+        raise Ft8GpuError(f"libft8gpu{'_ab' if suffix else ''}.so is stale or foreign: its build id is {have}, the sources beside it give {want} "
+                          "(rebuild: make -C rtlsdr_ft8d_amd/csrc" + (" ab)" if suffix else ")"))
+    return have
 
 
 def load_library():
@@ -94,6 +135,15 @@ def load_library():
             "(or __graft_entry__.build()).  There is no CPU fallback.")
     _lib = _declare(C.CDLL(LIB_PATH))
     return _lib
+
+
+def load_ab_library():
+    """the A/B build (product kernels + alternative kernel forms behind extra debug-flag bits), checked against the tree"""
+    if not os.path.exists(AB_LIB_PATH):
+        raise Ft8GpuError(f"{AB_LIB_PATH} is missing: build it with `make -C rtlsdr_ft8d_amd/csrc ab`")
+    L = load_library_at(AB_LIB_PATH)
+    check_build_id(L, "+ab")
+    return L
 
 
 def load_library_at(path):
@@ -123,6 +173,10 @@ def _declare(L):
     L.ft8gpu_decode_candidates.argtypes = [vp, vp, vp, vp, C.c_int, vp, C.c_int]
     L.ft8gpu_collect_spots.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int]
     L.ft8gpu_pack77_std.argtypes = [C.c_char_p, vp]
+    if hasattr(L, "ft8gpu_pack77"):                       # absent from older builds loaded by load_library_at
+        L.ft8gpu_pack77.argtypes = [C.c_char_p, vp]
+        L.ft8gpu_build_id.restype = C.c_char_p
+        L.ft8gpu_overlap_reason.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.ft8gpu_encode.argtypes = [vp, vp]
     L.ft8gpu_encode.restype = None
     L.ft8gpu_synth_frames.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, C.c_uint64, vp]
@@ -185,6 +239,16 @@ def pack77_std(msg):
     return out
 
 
+def pack77(msg):
+    """ft8gpu_pack77: any message type the packer knows (type 1 / 2 with grid, report, RRR / RR73 / 73, /R /P, CQ modifiers,
+    <hashed> calls; type 4; telemetry; free text) -> 10 bytes"""
+    out = np.zeros(10, np.uint8)
+    rc = load_library().ft8gpu_pack77(msg.encode(), out.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"cannot pack {msg!r} as an FT8 message")
+    return out
+
+
 def encode(payload):
     payload = np.ascontiguousarray(payload, np.uint8)
     tones = np.zeros(79, np.uint8)
@@ -201,8 +265,11 @@ class Decoder:
         self.params = Params(min_score, max_candidates, ldpc_iters)
         self.max_frames = max_frames
         h = C.c_void_p()
-        _check(self.lib.ft8gpu_create(C.byref(h), device, max_frames, C.byref(self.params)))
+        self._ck(self.lib.ft8gpu_create(C.byref(h), device, max_frames, C.byref(self.params)))
         self.h = h
+
+    def _ck(self, rc):
+        _check(rc, self.lib)            # the error text lives in the library that failed (the A/B build is a second library)
 
     def close(self):
         if getattr(self, "h", None):
@@ -225,7 +292,7 @@ class Decoder:
         p = Params(self.params.min_score if min_score is None else min_score,
                    self.params.max_candidates if max_candidates is None else max_candidates,
                    self.params.ldpc_iters if ldpc_iters is None else ldpc_iters)
-        _check(self.lib.ft8gpu_set_params(self.h, C.byref(p)))
+        self._ck(self.lib.ft8gpu_set_params(self.h, C.byref(p)))
         self.params = p
 
     def set_stream(self, stream_handle):
@@ -235,42 +302,47 @@ class Decoder:
             h = None
         else:
             h = int(stream_handle) or STREAM_LEGACY
-        _check(self.lib.ft8gpu_set_stream(self.h, C.c_void_p(h)))
+        self._ck(self.lib.ft8gpu_set_stream(self.h, C.c_void_p(h)))
 
     def stream_handle(self):
         """the hipStream_t of the context as an integer (e.g. for torch.cuda.ExternalStream)"""
         return int(self.lib.ft8gpu_get_stream(self.h) or 0)
 
     def set_debug_flags(self, flags):
-        _check(self.lib.ft8gpu_set_debug_flags(self.h, int(flags)))
+        self._ck(self.lib.ft8gpu_set_debug_flags(self.h, int(flags)))
 
     def overlap_active(self):
         """True: the two-part pipeline with the serial kernels on side streams is in use for large batches (the
-        context has SEEN its streams run kernels concurrently); False: plain pipeline (last_error() says why)"""
+        context has SEEN its streams run kernels concurrently); False: plain pipeline (overlap_reason() says why)"""
         return bool(self.lib.ft8gpu_overlap_active(self.h))
+
+    def overlap_reason(self):
+        buf = C.create_string_buffer(256)
+        self._ck(self.lib.ft8gpu_overlap_reason(self.h, buf, len(buf)))
+        return buf.value.decode()
 
     def selftest_bp_math(self):
         """exhaustive (2^32 inputs) comparison of the BP kernel's short division chains with the IEEE quotient"""
         out = (C.c_uint64 * 7)()
-        _check(self.lib.ft8gpu_selftest_bp_math(self.h, out))
+        self._ck(self.lib.ft8gpu_selftest_bp_math(self.h, out))
         keys = ("tanh_inputs", "tanh_mismatch", "atanh_inputs", "atanh_mismatch", "pair_mismatch", "tanh_max_bits", "first_bad")
         d = dict(zip(keys, [int(v) for v in out]))
         d["tanh_max"] = float(np.array([d["tanh_max_bits"]], np.uint32).view(np.float32)[0])
         return d
 
     def enable_timing(self, on=True):
-        _check(self.lib.ft8gpu_enable_timing(self.h, int(on)))
+        self._ck(self.lib.ft8gpu_enable_timing(self.h, int(on)))
 
     def timings(self):
         """mean per-stage milliseconds over the runs recorded since enable_timing(True)"""
         t, n = Timings(), C.c_int32(0)
-        _check(self.lib.ft8gpu_get_timings(self.h, C.byref(t), C.byref(n)))
+        self._ck(self.lib.ft8gpu_get_timings(self.h, C.byref(t), C.byref(n)))
         d = {k: getattr(t, k) for k, _ in Timings._fields_}
         d["runs"] = n.value
         return d
 
     def synchronize(self):
-        _check(self.lib.ft8gpu_synchronize(self.h))
+        self._ck(self.lib.ft8gpu_synchronize(self.h))
 
     # ---- host (numpy) API ------------------------------------------------------------------
     def decode_batch(self, iq, decodes=None):
@@ -280,7 +352,7 @@ class Decoder:
         if decodes is None:
             decodes = np.zeros((B, MAX_MESSAGES), RESULT_DTYPE)
         n = np.zeros(B, np.int32)
-        _check(self.lib.ft8gpu_decode_batch(self.h, iq.ctypes.data, B, decodes.ctypes.data, n.ctypes.data, HOST_PTRS))
+        self._ck(self.lib.ft8gpu_decode_batch(self.h, iq.ctypes.data, B, decodes.ctypes.data, n.ctypes.data, HOST_PTRS))
         return decodes, n
 
     def waterfall(self, iq):
@@ -288,7 +360,7 @@ class Decoder:
         B = iq.shape[0]
         assert iq.shape[1:] == (2, NSAMPLES)
         mag = np.zeros((B, MAG_ARRAY), np.uint8)
-        _check(self.lib.ft8gpu_waterfall(self.h, iq.ctypes.data, B, mag.ctypes.data, HOST_PTRS))
+        self._ck(self.lib.ft8gpu_waterfall(self.h, iq.ctypes.data, B, mag.ctypes.data, HOST_PTRS))
         return mag
 
     def find_sync(self, mag):
@@ -296,14 +368,14 @@ class Decoder:
         B = mag.shape[0]
         cands = np.zeros((B, self.max_candidates), CAND_DTYPE)
         counts = np.zeros(B, np.int32)
-        _check(self.lib.ft8gpu_find_sync(self.h, mag.ctypes.data, B, cands.ctypes.data, counts.ctypes.data, HOST_PTRS))
+        self._ck(self.lib.ft8gpu_find_sync(self.h, mag.ctypes.data, B, cands.ctypes.data, counts.ctypes.data, HOST_PTRS))
         return cands, counts
 
     def score_map(self, mag):
         mag = np.ascontiguousarray(mag, np.uint8).reshape(-1, MAG_ARRAY)
         B = mag.shape[0]
         s = np.zeros((B, 2, 2, 36, 249), np.int16)
-        _check(self.lib.ft8gpu_score_map(self.h, mag.ctypes.data, B, s.ctypes.data, HOST_PTRS))
+        self._ck(self.lib.ft8gpu_score_map(self.h, mag.ctypes.data, B, s.ctypes.data, HOST_PTRS))
         return s
 
     def decode_candidates(self, mag, cands, counts):
@@ -313,7 +385,7 @@ class Decoder:
         counts = np.ascontiguousarray(counts, np.int32)
         assert cands.shape == (B, self.max_candidates) and cands.dtype == CAND_DTYPE
         st = np.zeros((B, self.max_candidates), STATUS_DTYPE)
-        _check(self.lib.ft8gpu_decode_candidates(self.h, mag.ctypes.data, cands.ctypes.data, counts.ctypes.data,
+        self._ck(self.lib.ft8gpu_decode_candidates(self.h, mag.ctypes.data, cands.ctypes.data, counts.ctypes.data,
                                                  B, st.ctypes.data, HOST_PTRS))
         return st
 
@@ -325,32 +397,32 @@ class Decoder:
         if decodes is None:
             decodes = np.zeros((B, MAX_MESSAGES), RESULT_DTYPE)
         n = np.zeros(B, np.int32)
-        _check(self.lib.ft8gpu_collect_spots(self.h, cands.ctypes.data, counts.ctypes.data, status.ctypes.data, B,
+        self._ck(self.lib.ft8gpu_collect_spots(self.h, cands.ctypes.data, counts.ctypes.data, status.ctypes.data, B,
                                              decodes.ctypes.data, n.ctypes.data, HOST_PTRS))
         return decodes, n
 
     # ---- device-pointer API (inputs and outputs resident in HBM) --------------------------------
     def decode_batch_dev(self, iq_dev, nframes, decodes_dev, n_results_dev):
-        _check(self.lib.ft8gpu_decode_batch(self.h, _ptr(iq_dev), nframes, _ptr(decodes_dev), _ptr(n_results_dev),
+        self._ck(self.lib.ft8gpu_decode_batch(self.h, _ptr(iq_dev), nframes, _ptr(decodes_dev), _ptr(n_results_dev),
                                             DEVICE_PTRS))
 
     def find_sync_dev(self, mag_dev, nframes, cands_dev, counts_dev):
         """cands_dev: [nframes][max_candidates] 8-byte records, counts_dev: [nframes] int32 (all in HBM)"""
-        _check(self.lib.ft8gpu_find_sync(self.h, _ptr(mag_dev), nframes, _ptr(cands_dev), _ptr(counts_dev), DEVICE_PTRS))
+        self._ck(self.lib.ft8gpu_find_sync(self.h, _ptr(mag_dev), nframes, _ptr(cands_dev), _ptr(counts_dev), DEVICE_PTRS))
 
     def waterfall_dev(self, iq_dev, nframes, mag_dev):
-        _check(self.lib.ft8gpu_waterfall(self.h, _ptr(iq_dev), nframes, _ptr(mag_dev), DEVICE_PTRS))
+        self._ck(self.lib.ft8gpu_waterfall(self.h, _ptr(iq_dev), nframes, _ptr(mag_dev), DEVICE_PTRS))
 
     def rx_decimate(self, raw, normalise=True):
         """raw: uint8 [ncaptures][2*npairs] host array -> float32 [ncaptures][2][48000]"""
         raw = np.ascontiguousarray(raw, np.uint8)
         ncap, nbytes = raw.shape
         iq = np.zeros((ncap, 2, NSAMPLES), np.float32)
-        _check(self.lib.ft8gpu_rx_decimate(self.h, raw.ctypes.data, ncap, nbytes // 2, iq.ctypes.data, int(normalise), HOST_PTRS))
+        self._ck(self.lib.ft8gpu_rx_decimate(self.h, raw.ctypes.data, ncap, nbytes // 2, iq.ctypes.data, int(normalise), HOST_PTRS))
         return iq
 
     def rx_decimate_dev(self, raw_dev, ncaptures, npairs, iq_dev, normalise=True):
-        _check(self.lib.ft8gpu_rx_decimate(self.h, _ptr(raw_dev), ncaptures, npairs, _ptr(iq_dev), int(normalise), DEVICE_PTRS))
+        self._ck(self.lib.ft8gpu_rx_decimate(self.h, _ptr(raw_dev), ncaptures, npairs, _ptr(iq_dev), int(normalise), DEVICE_PTRS))
 
     def pskreporter_datagrams(self, decodes, n_results, info, unixtimes=None):
         """decodes: [n][50] RESULT_DTYPE, n_results: [n] -> (uint8 [n][DATAGRAM_STRIDE], int32 [n] lengths)"""
@@ -361,13 +433,13 @@ class Decoder:
         out = np.zeros((n, DATAGRAM_STRIDE), np.uint8)
         lengths = np.zeros(n, np.int32)
         t = None if unixtimes is None else np.ascontiguousarray(unixtimes, np.uint32)
-        _check(self.lib.ft8gpu_pskreporter_datagrams(self.h, decodes.ctypes.data, n_results.ctypes.data, n, C.byref(info),
+        self._ck(self.lib.ft8gpu_pskreporter_datagrams(self.h, decodes.ctypes.data, n_results.ctypes.data, n, C.byref(info),
                                                      None if t is None else t.ctypes.data, out.ctypes.data,
                                                      lengths.ctypes.data, HOST_PTRS))
         return out, lengths
 
     def pskreporter_datagrams_dev(self, decodes_dev, n_results_dev, nframes, info, unixtimes_dev, datagrams_dev, lengths_dev):
-        _check(self.lib.ft8gpu_pskreporter_datagrams(self.h, _ptr(decodes_dev), _ptr(n_results_dev), nframes, C.byref(info),
+        self._ck(self.lib.ft8gpu_pskreporter_datagrams(self.h, _ptr(decodes_dev), _ptr(n_results_dev), nframes, C.byref(info),
                                                      None if unixtimes_dev is None else _ptr(unixtimes_dev),
                                                      _ptr(datagrams_dev), _ptr(lengths_dev), DEVICE_PTRS))
 
@@ -375,7 +447,7 @@ class Decoder:
         """frame k of the call is global frame first_frame + k; its noise depends on (seed, global index) only"""
         signals = np.ascontiguousarray(signals)
         assert signals.dtype == SIGNAL_DTYPE and signals.size == nframes * nsig
-        _check(self.lib.ft8gpu_synth_frames_at(self.h, signals.ctypes.data, nframes, nsig, float(noise_sigma),
+        self._ck(self.lib.ft8gpu_synth_frames_at(self.h, signals.ctypes.data, nframes, nsig, float(noise_sigma),
                                                int(seed), int(first_frame), _ptr(iq_dev)))
 
     # ---- device memory helpers of the C ABI (a plain C caller has no HIP headers) ---------------
@@ -390,11 +462,11 @@ class Decoder:
 
     def memcpy_h2d(self, dst_dev, src):
         src = np.ascontiguousarray(src)
-        _check(self.lib.ft8gpu_memcpy_h2d(self.h, C.c_void_p(_ptr(dst_dev)), src.ctypes.data, src.nbytes))
+        self._ck(self.lib.ft8gpu_memcpy_h2d(self.h, C.c_void_p(_ptr(dst_dev)), src.ctypes.data, src.nbytes))
 
     def memcpy_d2h(self, dst, src_dev):
         assert dst.flags["C_CONTIGUOUS"]
-        _check(self.lib.ft8gpu_memcpy_d2h(self.h, dst.ctypes.data, C.c_void_p(_ptr(src_dev)), dst.nbytes))
+        self._ck(self.lib.ft8gpu_memcpy_d2h(self.h, dst.ctypes.data, C.c_void_p(_ptr(src_dev)), dst.nbytes))
 
 
 def decode_batch_multi(decoders, iq, decodes=None):
@@ -412,7 +484,9 @@ def decode_batch_multi(decoders, iq, decodes=None):
 
 
 class PinnedArray:
-    """numpy view of page-locked host memory from ft8gpu_host_alloc (freed by close() or at garbage collection)"""
+    """numpy view of page-locked host memory from ft8gpu_host_alloc.  The memory is freed by close() or at garbage
+    collection -- and close() REFUSES while other references to `array` (or views of it) are alive: a view that outlived
+    the allocation would be a use-after-free of unmapped pinned memory."""
 
     def __init__(self, shape, dtype=np.float32):
         lib = load_library()
@@ -420,12 +494,20 @@ class PinnedArray:
         self.ptr = lib.ft8gpu_host_alloc(self.nbytes)
         if not self.ptr:
             raise Ft8GpuError(lib.ft8gpu_last_error().decode(errors="replace"))
-        buf = (C.c_char * self.nbytes).from_address(self.ptr)
-        self.array = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._buf = (C.c_char * self.nbytes).from_address(self.ptr)
+        self._base = np.frombuffer(self._buf, dtype=dtype)          # every view of `array` keeps a reference to this object
+        self.array = self._base.reshape(shape)
 
     def close(self):
         if self.ptr:
+            import sys
             self.array = None
+            # references to the base array: self._base, getrefcount's argument -- anything beyond is a live view
+            extra = sys.getrefcount(self._base) - 2
+            if extra > 0:
+                raise Ft8GpuError(f"PinnedArray.close(): {extra} view(s) of the pinned buffer are still alive; drop them first")
+            self._base = None
+            self._buf = None
             load_library().ft8gpu_host_free(C.c_void_p(self.ptr))
             self.ptr = None
 

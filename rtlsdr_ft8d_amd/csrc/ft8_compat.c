@@ -2,8 +2,7 @@
  * ft8_compat.c -- host side of libft8gpu.so in C, as the reference is C:
  *   * the reference-named drop-in symbols ft8_subsystem / initFFTW / freeFFTW
  *     (rtlsdr_ft8d.h:155-156, :164; definitions rtlsdr_ft8d.c:314-347, :1387-1524)
- *   * the encoder tooling the self-test uses (pack77 for standard messages, ft8_encode:
- *     rtlsdr_ft8d.c:924-934; ft8_lib pack.c / encode.c / crc.c)
+ *     (the encoder tooling -- pack77, ft8_encode: rtlsdr_ft8d.c:924-934 -- lives in ft8_pack.c)
  *   * the .iq / .c2 replay readers and the .iq writer (rtlsdr_ft8d.c:744-856)
  *   * the ft8_lib-level symbols the reference's own ft8_subsystem() calls (ft8_find_sync, ft8_decode:
  *     rtlsdr_ft8d.c:1450, :1476; pack77, ft8_encode: :927, :934), declared in the headers under include/ft8_lib/ft8
@@ -12,9 +11,6 @@
 #define _GNU_SOURCE
 #include "../../include/ft8gpu.h"
 #include "../../include/ft8_lib/ft8/decode.h"
-#include "../../include/ft8_lib/ft8/pack.h"
-#include "../../include/ft8_lib/ft8/encode.h"
-#include "ft8_tables.h"
 
 #include <errno.h>
 #include <math.h>
@@ -205,121 +201,6 @@ bool ft8_decode(const waterfall_t *power, const candidate_t *cand, message_t *me
     }
     pthread_mutex_unlock(&g_lock);
     return ok;
-}
-
-int pack77(const char *msg, uint8_t *c77) {
-    uint8_t p[10];
-    if (ft8gpu_pack77_std(msg, p) != 0) return -1;
-    memcpy(c77, p, 10);                                    /* the 77-bit payload: 10 bytes, as upstream's pack77 fills (a caller may
-                                                              pass uint8_t[10]); ft8_encode reads no further */
-    return 0;
-}
-
-void ft8_encode(const uint8_t *payload, uint8_t *tones) { ft8gpu_encode(payload, tones); }
-
-/* ---------------------------------------------------------------------------------------------
- * encoder tooling: pack77 (standard messages) + CRC-14 + LDPC(174,91) generator + tone mapping
- * ------------------------------------------------------------------------------------------- */
-#define NTOKENS  2063592
-#define MAX22    4194304
-#define MAXGRID4 32400
-
-static int idx_in(const char *alphabet, char c) {
-    const char *p = strchr(alphabet, c);
-    return (p && c) ? (int)(p - alphabet) : -1;
-}
-
-static int32_t pack28_std(const char *call, int len) {
-    static const char A1[] = " 0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZ";
-    static const char A2[] = "0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZ";
-    static const char A3[] = "0123456789";
-    static const char A4[] = " ABCDEFGHIJKLMNOPQRSTUVWXYZ";
-    if (len == 2 && !strncmp(call, "DE", 2)) return 0;
-    if (len == 3 && !strncmp(call, "QRZ", 3)) return 1;
-    if (len == 2 && !strncmp(call, "CQ", 2)) return 2;
-    char c6[7] = "      ";
-    if (len >= 3 && len <= 6 && call[2] >= '0' && call[2] <= '9') memcpy(c6, call, (size_t)len);
-    else if (len >= 2 && len <= 5 && call[1] >= '0' && call[1] <= '9') memcpy(c6 + 1, call, (size_t)len);
-    else return -1;
-    const int i0 = idx_in(A1, c6[0]), i1 = idx_in(A2, c6[1]), i2 = idx_in(A3, c6[2]);
-    const int i3 = idx_in(A4, c6[3]), i4 = idx_in(A4, c6[4]), i5 = idx_in(A4, c6[5]);
-    if (i0 < 0 || i1 < 0 || i2 < 0 || i3 < 0 || i4 < 0 || i5 < 0) return -1;
-    int32_t n = i0;
-    n = n * 36 + i1;
-    n = n * 10 + i2;
-    n = n * 27 + i3;
-    n = n * 27 + i4;
-    n = n * 27 + i5;
-    return NTOKENS + MAX22 + n;
-}
-
-int ft8gpu_pack77_std(const char *msg, uint8_t payload[10]) {
-    if (!msg || !payload) return -1;
-    const char *s1 = strchr(msg, ' ');
-    if (!s1) return -1;
-    const char *c2 = s1 + 1;
-    const char *s2 = strchr(c2, ' ');
-    const int len1 = (int)(s1 - msg);
-    const int len2 = s2 ? (int)(s2 - c2) : (int)strlen(c2);
-    const int32_t na = pack28_std(msg, len1), nb = pack28_std(c2, len2);
-    if (na < 0 || nb < 0) return -1;
-    uint32_t igrid4 = MAXGRID4 + 1;                       /* no grid */
-    if (s2) {
-        const char *g = s2 + 1;                           /* only the first four locator characters count */
-        if (strlen(g) < 4 || g[0] < 'A' || g[0] > 'R' || g[1] < 'A' || g[1] > 'R' ||
-            g[2] < '0' || g[2] > '9' || g[3] < '0' || g[3] > '9') return -1;
-        igrid4 = (uint32_t)((((g[0] - 'A') * 18 + (g[1] - 'A')) * 10 + (g[2] - '0')) * 10 + (g[3] - '0'));
-    }
-    const uint64_t n29a = (uint64_t)na << 1, n29b = (uint64_t)nb << 1;
-    /* 29 + 29 + 1 (ir) + 15 (igrid4) + 3 (i3 = 1) = 77 bits, MSB first */
-    uint8_t b[10];
-    b[0] = (uint8_t)(n29a >> 21);
-    b[1] = (uint8_t)(n29a >> 13);
-    b[2] = (uint8_t)(n29a >> 5);
-    b[3] = (uint8_t)((n29a << 3) | (n29b >> 26));
-    b[4] = (uint8_t)(n29b >> 18);
-    b[5] = (uint8_t)(n29b >> 10);
-    b[6] = (uint8_t)(n29b >> 2);
-    b[7] = (uint8_t)((n29b << 6) | (igrid4 >> 10));
-    b[8] = (uint8_t)(igrid4 >> 2);
-    b[9] = (uint8_t)((igrid4 << 6) | (1u << 3));
-    memcpy(payload, b, 10);
-    return 0;
-}
-
-static uint16_t crc14(const uint8_t *msg, int nbits) {
-    uint32_t rem = 0;
-    for (int bit = 0, byte = 0; bit < nbits; ++bit) {
-        if ((bit & 7) == 0) rem ^= (uint32_t)msg[byte++] << 6;
-        rem = (rem & 0x2000u) ? (((rem << 1) ^ 0x2757u) & 0xFFFFu) : ((rem << 1) & 0xFFFFu);
-    }
-    return (uint16_t)(rem & 0x3FFFu);
-}
-
-void ft8gpu_encode(const uint8_t payload[10], uint8_t tones[FT8GPU_NN]) {
-    uint8_t a91[12];
-    memcpy(a91, payload, 10);
-    a91[9] &= 0xF8u;
-    a91[10] = a91[11] = 0;
-    const uint16_t crc = crc14(a91, 82);
-    a91[9] |= (uint8_t)(crc >> 11);
-    a91[10] = (uint8_t)(crc >> 3);
-    a91[11] = (uint8_t)(crc << 5);
-    uint8_t bits[174];
-    for (int i = 0; i < 91; ++i) bits[i] = (a91[i >> 3] >> (7 - (i & 7))) & 1;
-    for (int m = 0; m < 83; ++m) {
-        unsigned acc = 0;
-        for (int j = 0; j < 12; ++j) acc ^= (unsigned)(a91[j] & kFT8_generator[m][j]);
-        acc ^= acc >> 4; acc ^= acc >> 2; acc ^= acc >> 1;
-        bits[91 + m] = acc & 1;
-    }
-    int k = 0;
-    for (int t = 0; t < FT8GPU_NN; ++t) {
-        if (t < 7) tones[t] = kFT8_Costas[t];
-        else if (t >= 36 && t < 43) tones[t] = kFT8_Costas[t - 36];
-        else if (t >= 72) tones[t] = kFT8_Costas[t - 72];
-        else { tones[t] = kFT8_Gray[(bits[k] << 2) | (bits[k + 1] << 1) | bits[k + 2]]; k += 3; }
-    }
 }
 
 /* ---------------------------------------------------------------------------------------------

@@ -37,6 +37,18 @@ struct Ft8Tables {                 // device-resident constant tables, built on 
     float  qthr[260];              // quantiser thresholds: q(y) = #{k in 1..255 : y >= qthr[k]}
 };
 
+// Alternative, bit-identical kernel forms exist only in the A/B build of the library (make ab -> libft8gpu_ab.so,
+// -DFT8GPU_AB_FORMS): history to hold the product forms against (tools/ab_libs.py, tests/test_gpu_parity.py), not
+// shipped.  The two heap bits exclude each other.
+#ifdef FT8GPU_AB_FORMS
+#define FT8GPU_AB_WATERFALL_LDS        8u   /* last FFT stage: second exchange through LDS instead of register transposes across the wave's rows */
+#define FT8GPU_AB_HEAP_LANE_PER_FRAME 16u   /* heap replay: one lane per frame for every launch the cap allows (<= 128) */
+#define FT8GPU_AB_HEAP_WAVE_PER_FRAME 32u   /* heap replay: one wave per frame for every launch */
+constexpr unsigned kDbgAccepted = FT8GPU_DBG_ALL | 56u;
+#else
+constexpr unsigned kDbgAccepted = FT8GPU_DBG_ALL;
+#endif
+
 // kernel launchers (each enqueues on `s`, returns hipGetLastError())
 // debug_flags: the context's FT8GPU_DBG_* bits (kernel-form selectors are read by the launcher that owns the form)
 hipError_t launch_waterfall(const float *iq, uint8_t *mag, const Ft8Tables *tab, int nframes,

@@ -647,11 +647,14 @@ hipError_t launch_heap(const uint32_t *lists, const int32_t *list_counts, ft8gpu
     // One lane per frame (ft8_heap_simt_kernel) issues a tenth of the instructions but takes about 0.55 ms whatever the
     // number of frames (0.1-0.3 ms for the forms below): the batch pipeline asks for it when the kernels it runs beside
     // are long enough to cover that (latency_hidden), everybody else gets the short chain.
-    // (Test hooks, per context: FT8GPU_DBG_HEAP_LANE_PER_FRAME takes it whenever the cap allows, FT8GPU_DBG_HEAP_WAVE_PER_FRAME never.)
+    // (A/B build only: FT8GPU_AB_HEAP_LANE_PER_FRAME takes it whenever the cap allows, FT8GPU_AB_HEAP_WAVE_PER_FRAME never.)
     const bool lane_form_possible = max_candidates <= 128;
-    const bool want_lane_form = (debug_flags & FT8GPU_DBG_HEAP_LANE_PER_FRAME) ? true
-                              : (debug_flags & FT8GPU_DBG_HEAP_WAVE_PER_FRAME) ? false
-                              : (latency_hidden && nframes >= 256);
+    bool want_lane_form = latency_hidden && nframes >= 256;
+#ifdef FT8GPU_AB_FORMS
+    if (debug_flags & FT8GPU_AB_HEAP_LANE_PER_FRAME) want_lane_form = true;
+    if (debug_flags & FT8GPU_AB_HEAP_WAVE_PER_FRAME) want_lane_form = false;
+#endif
+    (void)debug_flags;
     if (lane_form_possible && want_lane_form) {
         hipLaunchKernelGGL(ft8_heap_simt_kernel, dim3((nframes + 63) / 64), dim3(64), (size_t)max_candidates * 64 * sizeof(uint32_t), s,
                            lists, list_counts, cands, counts, nframes, max_candidates);

@@ -125,7 +125,7 @@ __device__ __forceinline__ int xcd_item(int step, int nframes) {
 //                register against even rows of another) and v_permlane32_swap (upper half against lower half): one
 //                instruction per register, 32 per row of the waterfall, no select masks, no LDS.
 //   kStage4Lds   round 3's product: the exchange through LDS (16 ds_write_b64 + 8 ds_read_b128 per row, XOR-swizzled
-//                layout below), digit in the low lane bits.  Kept behind FT8GPU_DBG_WATERFALL_LDS as an independent
+//                layout below), digit in the low lane bits.  Instantiated in the A/B build only (FT8GPU_AB_WATERFALL_LDS) as an independent
 //                mechanism to hold the transposes against.
 // Both run the same butterflies in the same order: bit-identical output (test_waterfall_forms_are_bit_identical).
 // Measured, profiles/r04_waterfall_forms.json: 0.881 against 0.904 ms per 4096 frames alone, equal inside the pipeline;
@@ -327,7 +327,7 @@ void ft8_waterfall_kernel(const float *__restrict__ iq, uint8_t *__restrict__ ma
 
 }  // namespace
 
-// FT8GPU_DBG_WATERFALL_LDS selects the form with the second exchange through LDS; the product is the row-transpose form
+// the product is the row-transpose form; the A/B build (FT8GPU_AB_FORMS) also holds the form with the second exchange through LDS
 hipError_t launch_waterfall(const float *iq, uint8_t *mag, const Ft8Tables *tab, int nframes,
                             int num_cus, unsigned debug_flags, hipStream_t s) {
     const int nitems = nframes * kWfItemsPerFrame;
@@ -336,9 +336,13 @@ hipError_t launch_waterfall(const float *iq, uint8_t *mag, const Ft8Tables *tab,
     if (grid < 1) return hipSuccess;
     // XCD-aware order needs whole groups of 8 workgroups and enough frames to give every XCD work
     const int xo = (grid % 8 == 0 && nframes >= 64) ? 1 : 0;
-    if (debug_flags & FT8GPU_DBG_WATERFALL_LDS)
+#ifdef FT8GPU_AB_FORMS
+    if (debug_flags & FT8GPU_AB_WATERFALL_LDS) {
         hipLaunchKernelGGL(ft8_waterfall_kernel<kStage4Lds>, dim3(grid), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xo);
-    else
-        hipLaunchKernelGGL(ft8_waterfall_kernel<kStage4Rows>, dim3(grid), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xo);
+        return hipGetLastError();
+    }
+#endif
+    (void)debug_flags;
+    hipLaunchKernelGGL(ft8_waterfall_kernel<kStage4Rows>, dim3(grid), dim3(256), 0, s, iq, mag, tab, nitems, nframes, xo);
     return hipGetLastError();
 }

@@ -26,7 +26,18 @@ def _bits(fields):
     return (v << 3).to_bytes(10, "big")
 
 
+def call_hash(call, bits):
+    """the m-bit hash of a call sign: the call left-justified in 11 characters as a base-38 number, multiplied by
+    47055833459 modulo 2^64, top m bits (m = 22 in type 1 / 2 messages, 12 in type 4)"""
+    n = 0
+    for c in call.ljust(11):
+        n = n * 38 + A_CALL11.index(c)
+    return ((47055833459 * n) & 0xFFFFFFFFFFFFFFFF) >> (64 - bits)
+
+
 def pack28(token):
+    if token.startswith("<") and token.endswith(">"):
+        return NTOKENS + call_hash(token[1:-1], 22)
     if token == "DE":
         return 0
     if token == "QRZ":
@@ -43,6 +54,10 @@ def pack28(token):
             m = m * 27 + A_LETTER_SP.index(c)
         return 1003 + m
     call = token
+    if call.startswith("3DA0"):
+        call = "3D0" + call[4:]
+    elif call.startswith("3X") and call[2].isalpha():
+        call = "Q" + call[2:]
     if len(call) >= 3 and call[2].isdigit():
         c6 = call.ljust(6)
     else:

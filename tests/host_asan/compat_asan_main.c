@@ -1,6 +1,6 @@
 /*
- * Host-only sanitizer harness for csrc/ft8_compat.c (pack77 / ft8_encode / .iq and .c2 readers / printSpots
- * formatter / the drop-in shim): compiled with gcc -fsanitize=address,undefined together with ft8_compat.c and
+ * Host-only sanitizer harness for csrc/ft8_compat.c and csrc/ft8_pack.c (pack77 / ft8_encode / .iq and .c2 readers /
+ * printSpots formatter / the drop-in shim): compiled with gcc -fsanitize=address,undefined together with both and
  * run by tests/test_sanitizers.py on the CPU box (GPU AddressSanitizer is not available on the pool).
  * The four ft8gpu_* entry points the shim calls live in the HIP half of the library; here they are replaced
  * by failing definitions, which also drives the shim's "no GPU" path (*n_results = 0, reason on stderr).
@@ -58,6 +58,32 @@ int main(int argc, char **argv) {
         if (ft8gpu_pack77_std(bad[i], q) == 0) ft8gpu_encode(q, tones);
     }
     CHECK(ft8gpu_pack77_std(NULL, p) != 0 && ft8gpu_pack77_std("CQ K1JT FN20", NULL) != 0);
+    /* the full packer (csrc/ft8_pack.c): every bad[] text again, hand-picked edge shapes, and 200 000 random strings over
+     * the characters its parsers branch on -- whatever it accepts must encode, nothing may read or write out of bounds */
+    static const char *edge[] = { "<", ">", "<>", "<> <>", "< > K1ABC", "<K1ABC", "K1ABC>", "<K1ABC> <W9XYZ>", "<ABCDEFGHIJKL> K1ABC", "CQ <K1ABC>",
+                                  "CQ 000 K1ABC", "CQ 999 K1ABC FN20", "CQ ZZZZ K1ABC", "CQ ABCDE K1ABC", "CQ K1ABC/R", "CQ K1ABC/P FN20", "/R /P", "K1ABC/ W9XYZ",
+                                  "K1ABC W9XYZ R", "K1ABC W9XYZ R R", "K1ABC W9XYZ R FN2", "K1ABC W9XYZ +00", "K1ABC W9XYZ -30", "K1ABC W9XYZ -31", "K1ABC W9XYZ R+99",
+                                  "K1ABC W9XYZ +100", "K1ABC W9XYZ FN20QIX", "K1ABC W9XYZ FN20Q!", "3DA0", "3DA0XYZW K1ABC", "3X K1ABC", "3XA0XYZW K1ABC FN20",
+                                  "7FFFFFFFFFFFFFFFFF", "8000000000000000000", "FFFFFFFFFFFFFFFFF", "CQ ABCDEFGHIJK", "CQ ABCDEFGHIJKL", "CQ A", "CQ /",
+                                  "A/B/C/D/E/F <K1ABC> 73", "<K1ABC> A/B/C/D/E/F RR73 ", "             ", "1234567890123", "12345678901234", "+-./?", "a", "\x01" };
+    CHECK(ft8gpu_pack77(NULL, p) != 0 && ft8gpu_pack77("CQ K1JT FN20", NULL) != 0);
+    for (size_t i = 0; i < sizeof bad / sizeof bad[0]; i++) if (ft8gpu_pack77(bad[i], p) == 0) ft8gpu_encode(p, tones);
+    for (size_t i = 0; i < sizeof edge / sizeof edge[0]; i++) if (ft8gpu_pack77(edge[i], p) == 0) ft8gpu_encode(p, tones);
+    {
+        static const char pool[] = "  KW19ABCXYZR73<>/+-?.QDEFN20P";
+        uint64_t s = 0x2545F4914F6CDD1Dull;
+        int accepted = 0;
+        for (int it = 0; it < 200000; it++) {
+            char text[48];
+            s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+            const int len = (int)(s % 45);
+            uint64_t r = s;
+            for (int k = 0; k < len; k++) { r = r * 6364136223846793005ull + 1442695040888963407ull; text[k] = pool[(r >> 33) % (sizeof pool - 1)]; }
+            text[len] = 0;
+            if (ft8gpu_pack77(text, p) == 0) { ft8gpu_encode(p, tones); accepted++; CHECK((p[9] & 7) == 0); }
+        }
+        CHECK(accepted > 1000);
+    }
 
     /* file formats: full, truncated, empty and missing files (rtlsdr_ft8d.c:744-856) */
     float *I = malloc(sizeof(float) * FT8GPU_NSAMPLES), *Q = malloc(sizeof(float) * FT8GPU_NSAMPLES);

@@ -179,3 +179,38 @@ def test_gather_entry_argument_errors_and_no_rccl_link_dependency(ft8):
     assert "rccl" not in out and "nccl" not in out
     lib.ft8gpu_gather_shutdown()                       # harmless without communicators
     assert lib.ft8gpu_shard_workers() == 0             # no worker thread until a multi-GPU call needs one
+
+
+def test_build_id_ties_the_library_to_the_sources(ft8, tmp_path):
+    """ft8gpu_build_id() is the hash the Makefile took over the sources at link time; the binding recomputes it from the
+    tree, so a stale or foreign .so is refused (smoke(), bench.py and the GPU tests call check_build_id)."""
+    lib = ft8.load_library()
+    have = lib.ft8gpu_build_id().decode()
+    assert re.fullmatch(r"[0-9a-f]{16}\.[0-9a-f]{16}", have), have
+    assert have == ft8.source_build_id() == ft8.check_build_id()
+    assert have.split(".")[0] == ft8.device_source_id()
+    # the shipped library has no alternative kernel forms: those live in the A/B build, whose id says so
+    if os.path.exists(ft8.AB_LIB_PATH):
+        assert ft8.build_id(ft8.load_ab_library()) == have + "+ab"
+    # a library from other sources is refused: same tree, one byte more in a kernel source
+    import shutil
+    fake = tmp_path / "pkg"
+    shutil.copytree(os.path.join(ROOT, "rtlsdr_ft8d_amd"), fake / "rtlsdr_ft8d_amd", ignore=shutil.ignore_patterns("build*", "__pycache__"))
+    shutil.copytree(os.path.join(ROOT, "include"), fake / "include")
+    with open(fake / "rtlsdr_ft8d_amd" / "csrc" / "spots.hip", "a") as f:
+        f.write("\n// edited after the library was built\n")
+    code = ("import sys; sys.path.insert(0, %r); import rtlsdr_ft8d_amd as m\n"
+            "try:\n    m.check_build_id()\nexcept m.Ft8GpuError as e:\n    print('REFUSED', e)\n" % str(fake))
+    out = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "REFUSED" in out.stdout and "stale or foreign" in out.stdout, out.stdout + out.stderr
+
+
+def test_pure_queries_leave_the_error_state_alone(ft8):
+    """ft8gpu_overlap_active / ft8gpu_overlap_reason report through their own channel (round 4's getter overwrote
+    ft8gpu_last_error() on success)"""
+    lib = ft8.load_library()
+    assert lib.ft8gpu_gather_spots(None, 0, None, None, 4, None, None) == -1
+    before = lib.ft8gpu_last_error()
+    buf = C.create_string_buffer(64)
+    assert lib.ft8gpu_overlap_reason(None, buf, 64) == -1 and b"ctx is NULL" in lib.ft8gpu_last_error()
+    assert before != lib.ft8gpu_last_error()

@@ -579,6 +579,8 @@ def test_bp_division_chains_by_exhaustion():
     with ft8.Decoder(device=0, max_frames=1) as d:
         with pytest.raises(ft8.Ft8GpuError, match="unknown bits"):
             d.set_debug_flags(64)
+        with pytest.raises(ft8.Ft8GpuError, match="unknown bits"):
+            d.set_debug_flags(16)            # kernel-form selectors exist in the A/B build only
 
 
 def test_decode_pipeline_form_of_the_kernel(oracle):
@@ -825,12 +827,12 @@ def test_decode_randomised_waterfall_sweep(oracle, gpu_decoder):
     assert total == 3840
 
 
-@pytest.mark.parametrize("form", ["rows", "lds"])
+@pytest.mark.parametrize("form", ["rows", "ab-rows", "ab-lds"])
 def test_waterfall_forms_are_bit_identical(oracle, form):
     """Both forms of the last FFT stage -- 4 x 4 register transposes across the wave's rows with v_permlane16/32_swap
-    (the product) and the exchange through LDS (FT8GPU_DBG_WATERFALL_LDS) -- must produce the oracle's bytes.  The form
-    is a per-context flag, so one process runs both (round 3 needed a child process per form: the switch was an
-    environment variable)."""
+    (the product) and the exchange through LDS -- must produce the oracle's bytes.  The LDS form is not in the shipped
+    library any more: it is compiled into the A/B build (libft8gpu_ab.so, -DFT8GPU_AB_FORMS) and selected there by a
+    per-context flag; the same test runs the product library, the A/B build's product form and its LDS form."""
     import rtlsdr_ft8d_amd as ft8
     import synth_util as S
     enc = S.oracle_encode_fn(oracle)
@@ -839,9 +841,13 @@ def test_waterfall_forms_are_bit_identical(oracle, form):
     rng = np.random.default_rng(2)
     big = rng.normal(0, 0.2, (300, 2, 48000)).astype(np.float32)      # enough frames for the XCD-aware work order
     iq = np.concatenate([np.stack(fr), big])
-    flags = {"rows": 0, "lds": ft8.DBG_WATERFALL_LDS}[form]
-    with ft8.Decoder(device=0, max_frames=iq.shape[0]) as d:
-        d.set_debug_flags(flags)
+    lib = None if form == "rows" else ft8.load_ab_library()
+    with ft8.Decoder(device=0, max_frames=iq.shape[0], lib=lib) as d:
+        if form == "ab-lds":
+            d.set_debug_flags(ft8.AB_WATERFALL_LDS)
+        if form == "rows":
+            with pytest.raises(ft8.Ft8GpuError, match="unknown bits"):      # the shipped library has no such form
+                d.set_debug_flags(ft8.AB_WATERFALL_LDS)
         mag = d.waterfall(iq)
         dec, n = d.decode_batch(iq[:5])
     for k in list(range(5)) + [5, 100, 304]:
@@ -879,7 +885,8 @@ def test_gpu_against_the_independent_numpy_restatement(gpu_decoder, frames, orac
 def test_heap_forms_are_exact(oracle, form):
     """ft8_heap_simt_kernel (one lane per frame; the batch pipeline uses it from 3072 frames on) and the wave-per-frame
     kernel must both return the reference's candidate lists -- order included: each is forced for every launch with its
-    per-context flag and compared with the oracle at several caps, thresholds and ragged frame counts"""
+    per-context flag of the A/B build (the shipped library picks the form by launch size and has no such flags) and
+    compared with the oracle at several caps, thresholds and ragged frame counts"""
     import rtlsdr_ft8d_amd as ft8
     import synth_util as S
     enc = S.oracle_encode_fn(oracle)
@@ -889,8 +896,8 @@ def test_heap_forms_are_exact(oracle, form):
     mags = [oracle.waterfall(f[0], f[1]) for f in fr] + [rng.integers(0, 256, 94208, dtype=np.uint8) for _ in range(70)]   # 77 frames: two waves, ragged
     mag = np.stack(mags)
     bad = []
-    with ft8.Decoder(device=0, max_frames=len(mags)) as d:
-        d.set_debug_flags(ft8.DBG_HEAP_LANE_PER_FRAME if form == "lane" else ft8.DBG_HEAP_WAVE_PER_FRAME)
+    with ft8.Decoder(device=0, max_frames=len(mags), lib=ft8.load_ab_library()) as d:
+        d.set_debug_flags(ft8.AB_HEAP_LANE_PER_FRAME if form == "lane" else ft8.AB_HEAP_WAVE_PER_FRAME)
         for cap, ms in ((120, 10), (128, 10), (7, 10), (1, 10), (33, 0), (120, -5), (64, 30)):
             d.set_params(min_score=ms, max_candidates=cap)
             cands, counts = d.find_sync(mag)
@@ -899,5 +906,5 @@ def test_heap_forms_are_exact(oracle, form):
                 if counts[k] != len(ref) or not np.array_equal(cands[k, :counts[k]], ref) or cands[k, counts[k]:].tobytes().strip(b"\0"):
                     bad.append((cap, ms, k))
         with pytest.raises(ft8.Ft8GpuError, match="exclude each other"):
-            d.set_debug_flags(ft8.DBG_HEAP_LANE_PER_FRAME | ft8.DBG_HEAP_WAVE_PER_FRAME)
+            d.set_debug_flags(ft8.AB_HEAP_LANE_PER_FRAME | ft8.AB_HEAP_WAVE_PER_FRAME)
     assert not bad, bad[:5]
