@@ -93,6 +93,10 @@ def parse_args(argv=None):
     ap.add_argument("--debug-flags", type=int, default=0,
                     help="FT8GPU_DBG_* bits for the decoder context (profiling of the non-product kernel forms; reported in the line, 0 = product)")
     ap.add_argument("--shards", type=int, default=8, help="configs[3] on one GPU: number of contexts / shards")
+    ap.add_argument("--traffic", choices=("cq", "mixed"), default="cq",
+                    help="message pool of the synthetic frames: cq = 'CQ call grid' only (SURVEY.md 8(d), the headline); mixed = what a receiver "
+                         "meets on the air (workload.mixed_message_pool: about a quarter CQ calls, the rest QSO traffic of every message type, one "
+                         "frame in four with a message heard twice) -- a side line, reported as such")
     return ap.parse_args(argv)
 
 
@@ -245,6 +249,8 @@ def main():
     snr = tuple(args.snr) if args.snr else cfg["snr"]
     maxc = args.max_candidates or cfg["max_candidates"]
     label = cfg["label"].format(B=B, S=nsig, lo=snr[0], hi=snr[1], C=maxc)
+    if args.traffic == "mixed":
+        label = label.replace("CQ signals/frame", "signals/frame of MIXED traffic (not the headline recipe: ~22 % CQ calls, QSO messages of every type, duplicates)")
 
     import torch
     import torch.distributed as dist
@@ -346,10 +352,12 @@ def main():
     torch.cuda.set_stream(coll_stream)
 
     # ---- synthetic frames, generated in HBM (not timed); global frame g is the same samples for any world size
-    _, pool_tones = workload.message_pool()
-    sig, _ = workload.frame_signals(lo, B, nsig, pool_tones, snr_range=snr)
+    _, pool_tones = workload.message_pool(traffic=args.traffic)
+    sig, _ = workload.frame_signals(lo, B, nsig, pool_tones, snr_range=snr,
+                                    dup_fraction=workload.MIXED_DUP_FRACTION if args.traffic == "mixed" else 0.0)
     iq = torch.empty((B, 2, ft8.NSAMPLES), dtype=torch.float32, device=dev)
     dec.synth_frames(sig, B, nsig, 1.0, workload.SEED_BASE, iq, first_frame=lo)
+    out["config"]["traffic"] = args.traffic
 
     if args.config == 1:
         run_config1(args, out, dec, iq, B, maxc, stream, dev)
@@ -419,6 +427,11 @@ def main():
         out["gpu_clock"]["frames_per_joule"] = round((total / max(world, 1)) * args.steps / elapsed / pw, 1)
     out["prewarm_steps"] = args.prewarm        # untimed, before the W warm-up steps (clock ramp after idle; see --prewarm)
     out["config"]["decoded_messages_per_frame"] = round(float(nres.cpu().numpy().mean()), 2)
+    # slots the path wrote (messages whose first token starts with "CQ", rtlsdr_ft8d.c:1509-1519); the other messages are
+    # counted in n_results and leave their slot as the caller's array had it (zeros here)
+    rec = spots.view(B, ft8.MAX_MESSAGES, 28)
+    used = torch.arange(ft8.MAX_MESSAGES, device=dev)[None, :] < nres[:, None]
+    out["config"]["cq_spots_per_frame"] = round(float(((rec != 0).any(dim=2) & used).sum().item()) / B, 2)
     if use_dist and world > 1:
         # the gathered list of the last step must hold every rank's records in global frame order
         gs, gc = exch.gathered(state["k"] - 1)
@@ -658,9 +671,13 @@ def usable_cores():
 
 
 def cpu_baseline(iq, spots, nres, m, max_candidates):
-    """The CPU oracle (a port of the reference path; the reference itself cannot be built here) timed
-    on the first m frames of the same batch, all host cores, one frame per OpenMP task.  The same
-    sample doubles as a parity check of the GPU results."""
+    """The reference's path on the host cores, timed on the first m frames of the same batch, one frame per OpenMP task.
+    The reference itself cannot be built here (ft8_lib submodule empty, no fftw3.h), so everything behind the FFT is
+    the oracle's restatement either way.  The FFT is DETECTED, not assumed: when libfftw3f.so.3 is on the box the oracle
+    binds it at run time and transforms as the reference does (fftwf_plan_dft_1d(1024, FFTW_FORWARD, FFTW_ESTIMATE),
+    rtlsdr_ft8d.c:326; executed per row, :1411) -> kind "reference-fft", with the flips against the oracle's own radix-4
+    FFT counted; otherwise kind "port" with the library names that were searched.  The same sample doubles as a parity
+    check of the GPU results."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     import rtlsdr_ft8d_amd as ft8
@@ -679,11 +696,33 @@ def cpu_baseline(iq, spots, nres, m, max_candidates):
     g_dec = spots[:m].cpu().numpy().view(ft8.RESULT_DTYPE).reshape(m, ft8.MAX_MESSAGES)
     g_n = nres[:m].cpu().numpy()
     same = sum(int(g_n[k] == rn[k] and g_dec[k].tobytes() == rdec[k].tobytes()) for k in range(m))
-    return {"value": round(m / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"first {m} frames of the bench batch through oracle ft8o_subsystem_batch (gcc -O3 -ffp-contract=off, own radix-4 FFT "
-                      f"-- fftw3f is not installed on the box --, OpenMP {cores} threads), {dt:.2f} s wall",
+    port = {"value": round(m / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"first {m} frames of the bench batch through oracle ft8o_subsystem_batch (gcc -O3 -ffp-contract=off, the oracle's own radix-4 "
+                      f"FFT, OpenMP {cores} threads), {dt:.2f} s wall",
             "single_core_frames_per_s": round(m1 / dt1, 2), "os_cpu_count": os.cpu_count(),
             "gpu_vs_oracle_identical_frames": f"{same}/{m}"}
+    have_fftw, detail = oracle_lib.fftw_init(None)
+    if not have_fftw:
+        port["fftw3f"] = f"not found (searched: {detail})"
+        return port
+    oracle_lib.subsystem_batch_fftw(host_iq[:min(m, cores)], p, cores)
+    t2 = time.perf_counter()
+    fdec, fn = oracle_lib.subsystem_batch_fftw(host_iq, p, cores)
+    dtf = time.perf_counter() - t2
+    t3 = time.perf_counter()
+    oracle_lib.subsystem_batch_fftw(host_iq[:m1], p, 1)
+    dtf1 = time.perf_counter() - t3
+    mw = min(m, 256)
+    wf_fftw = oracle_lib.waterfall_batch(host_iq[:mw], 2, cores)
+    wf_own = oracle_lib.waterfall_batch(host_iq[:mw], False, cores)
+    same_f = sum(int(fn[k] == rn[k] and fdec[k].tobytes() == rdec[k].tobytes()) for k in range(m))
+    return {"value": round(m / dtf, 2), "unit": "frames/s", "cores": cores, "kind": "reference-fft",
+            "sample": f"first {m} frames of the bench batch: the reference's FFT (fftw3f bound at run time from {detail}: fftwf_plan_dft_1d 1024 FFTW_FORWARD "
+                      f"FFTW_ESTIMATE, one fftwf_execute_dft per row) + the oracle's restatement of everything behind it, OpenMP {cores} threads, {dtf:.2f} s wall",
+            "single_core_frames_per_s": round(m1 / dtf1, 2), "os_cpu_count": os.cpu_count(), "fftw3f": detail,
+            "fft_flips_vs_own_radix4": {"waterfall_bytes_differing": int((wf_fftw != wf_own).sum()), "of_bytes": int(wf_own.size),
+                                        "frames_with_different_records": m - same_f, "of_frames": m},
+            "port_with_own_fft": port, "gpu_vs_oracle_identical_frames": f"{same}/{m}"}
 
 
 def host_legs(dec, iq, spots, nres, B):

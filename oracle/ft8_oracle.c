@@ -10,6 +10,7 @@
 #include "ft8_oracle.h"
 #include "ft8o_tables.h"
 
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -194,6 +195,94 @@ void ft8o_waterfall(const float *iSamples, const float *qSamples, uint8_t *mag_p
                     mag_power[offset++] = q[pos * FT8O_K_FREQ_OSR + freq_sub];
         }
     }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Optional run-time FFTW leg: the reference's OWN transform where the box has it.
+ * The reference plans fftwf_plan_dft_1d(NFFT, fft_in, fft_out, FFTW_FORWARD, PATIENCE) with PATIENCE = FFTW_ESTIMATE
+ * (rtlsdr_ft8d.c:326, rtlsdr_ft8d.h:65) on fftwf_malloc'ed buffers (:322-323) and runs fftwf_execute per row (:1411).
+ * libfftw3f is not linked (this image has neither the library nor fftw3.h): it is bound with dlopen, its five
+ * prototypes declared by hand from FFTW's documented API.  Rows are transformed with fftwf_execute_dft on per-thread
+ * fftwf_malloc'ed buffers -- the documented thread-safe form of fftwf_execute, same plan, same alignment, same
+ * arithmetic -- so that the batch runs one frame per thread like the other legs.  FFTW's float butterflies are not
+ * R4DIF's: a waterfall byte may differ by one step where |X|^2 sits on a quantiser threshold (the same effect the
+ * float64 leg measures, tools/fft_parity.py); bench.py reports the flip counts next to the rate.
+ * ---------------------------------------------------------------------------------------- */
+typedef float ft8o_fftwf_complex[2];
+static struct {
+    int tried, ok;
+    void *lib, *plan;
+    void *(*malloc_)(size_t);
+    void (*free_)(void *);
+    void *(*plan_dft_1d)(int, ft8o_fftwf_complex *, ft8o_fftwf_complex *, int, unsigned);
+    void (*execute_dft)(void *, ft8o_fftwf_complex *, ft8o_fftwf_complex *);
+    void (*destroy_plan)(void *);
+    char detail[768];
+} g_fftw;
+
+/* 1: libfftw3f is bound and the reference's plan exists; 0: not found (ft8o_fftw_detail() lists what was searched).
+ * explicit_path: tried first when not NULL (tests); NULL = the system's library only. */
+int ft8o_fftw_init(const char *explicit_path) {
+    if (g_fftw.tried) return g_fftw.ok;
+    g_fftw.tried = 1;
+    static const char *names[] = { "libfftw3f.so.3", "libfftw3f.so", "/usr/lib/x86_64-linux-gnu/libfftw3f.so.3", "/usr/lib64/libfftw3f.so.3",
+                                   "/usr/local/lib/libfftw3f.so.3", "/opt/conda/lib/libfftw3f.so.3" };
+    size_t at = 0;
+    const char *found = NULL;
+    if (explicit_path && (g_fftw.lib = dlopen(explicit_path, RTLD_NOW | RTLD_LOCAL))) found = explicit_path;
+    for (size_t i = 0; !g_fftw.lib && i < sizeof names / sizeof names[0]; i++) {
+        if ((g_fftw.lib = dlopen(names[i], RTLD_NOW | RTLD_LOCAL))) { found = names[i]; break; }
+        at += (size_t)snprintf(g_fftw.detail + at, at < sizeof g_fftw.detail ? sizeof g_fftw.detail - at : 0, "%s%s", i ? ", " : "", names[i]);
+        if (at >= sizeof g_fftw.detail) at = sizeof g_fftw.detail - 1;
+    }
+    if (!g_fftw.lib) return 0;
+    g_fftw.malloc_ = (void *(*)(size_t))dlsym(g_fftw.lib, "fftwf_malloc");
+    g_fftw.free_ = (void (*)(void *))dlsym(g_fftw.lib, "fftwf_free");
+    g_fftw.plan_dft_1d = (void *(*)(int, ft8o_fftwf_complex *, ft8o_fftwf_complex *, int, unsigned))dlsym(g_fftw.lib, "fftwf_plan_dft_1d");
+    g_fftw.execute_dft = (void (*)(void *, ft8o_fftwf_complex *, ft8o_fftwf_complex *))dlsym(g_fftw.lib, "fftwf_execute_dft");
+    g_fftw.destroy_plan = (void (*)(void *))dlsym(g_fftw.lib, "fftwf_destroy_plan");
+    if (!g_fftw.malloc_ || !g_fftw.free_ || !g_fftw.plan_dft_1d || !g_fftw.execute_dft || !g_fftw.destroy_plan) {
+        snprintf(g_fftw.detail, sizeof g_fftw.detail, "%s lacks a required fftwf_* symbol", found);
+        return 0;
+    }
+    ft8o_fftwf_complex *in = (ft8o_fftwf_complex *)g_fftw.malloc_(sizeof(ft8o_fftwf_complex) * FT8O_NFFT);     /* :322-323 */
+    ft8o_fftwf_complex *out = (ft8o_fftwf_complex *)g_fftw.malloc_(sizeof(ft8o_fftwf_complex) * FT8O_NFFT);
+    if (in && out) g_fftw.plan = g_fftw.plan_dft_1d(FT8O_NFFT, in, out, -1 /* FFTW_FORWARD */, 1u << 6 /* FFTW_ESTIMATE */);   /* :326 */
+    if (in) g_fftw.free_(in);                          /* the plan is executed on other buffers of the same alignment */
+    if (out) g_fftw.free_(out);
+    if (!g_fftw.plan) { snprintf(g_fftw.detail, sizeof g_fftw.detail, "%s: fftwf_plan_dft_1d failed", found); return 0; }
+    snprintf(g_fftw.detail, sizeof g_fftw.detail, "%s", found);
+    g_fftw.ok = 1;
+    return 1;
+}
+const char *ft8o_fftw_detail(void) { return g_fftw.detail; }
+
+/* rtlsdr_ft8d.c:1395-1435 with the reference's own FFT; returns 0, or -1 when FFTW is not bound */
+int ft8o_waterfall_fftw(const float *iSamples, const float *qSamples, uint8_t *mag_power) {
+    ft8o_init();
+    if (!g_fftw.ok) return -1;
+    ft8o_fftwf_complex *in = (ft8o_fftwf_complex *)g_fftw.malloc_(sizeof(ft8o_fftwf_complex) * FT8O_NFFT);
+    ft8o_fftwf_complex *out = (ft8o_fftwf_complex *)g_fftw.malloc_(sizeof(ft8o_fftwf_complex) * FT8O_NFFT);
+    if (!in || !out) { if (in) g_fftw.free_(in); if (out) g_fftw.free_(out); return -1; }
+    int offset = 0;
+    for (int idx_block = 0; idx_block < FT8O_NUM_BLOCKS; ++idx_block) {
+        for (int time_sub = 0; time_sub < FT8O_K_TIME_OSR; ++time_sub) {
+            const int start = idx_block * FT8O_BLOCK_SIZE + time_sub * FT8O_SUB_BLOCK_SIZE;
+            for (int i = 0; i < FT8O_NFFT; ++i) {                       /* :1407-1410 */
+                in[i][0] = iSamples[start + i] * g_hann[i];
+                in[i][1] = qSamples[start + i] * g_hann[i];
+            }
+            g_fftw.execute_dft(g_fftw.plan, in, out);                   /* :1411 */
+            for (int freq_sub = 0; freq_sub < FT8O_K_FREQ_OSR; ++freq_sub)   /* :1414-1433 */
+                for (int pos = 0; pos < FT8O_NUM_BIN; ++pos) {
+                    const int k = pos * FT8O_K_FREQ_OSR + freq_sub;
+                    mag_power[offset++] = ft8o_quantise(out[k][0] * out[k][0] + out[k][1] * out[k][1]);
+                }
+        }
+    }
+    g_fftw.free_(in);
+    g_fftw.free_(out);
+    return 0;
 }
 
 /* same path with the DFT carried out in float64 (window product still float, as the reference) */
@@ -1091,6 +1180,28 @@ void ft8o_subsystem_batch(const float *iq, int B, const ft8o_params_t *p,
     (void)nthreads;
 }
 
+/* ft8o_subsystem_batch with the reference's own FFT (fftw3f bound at run time): the CPU baseline "reference-fft" of
+ * bench.py.  Returns -1 without touching the outputs when FFTW is not bound. */
+int ft8o_subsystem_batch_fftw(const float *iq, int B, const ft8o_params_t *p,
+                              struct ft8o_decoder_results *decodes, int32_t *n_results, int nthreads) {
+    ft8o_init();
+    if (!g_fftw.ok) return -1;
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+#endif
+    for (int f = 0; f < B; f++) {
+        const float *I = iq + (size_t)f * 2 * FT8O_NSAMPLES;
+        uint8_t *mag_power = (uint8_t *)malloc(FT8O_MAG_ARRAY);
+        if (mag_power && ft8o_waterfall_fftw(I, I + FT8O_NSAMPLES, mag_power) == 0)
+            spots_from_waterfall(mag_power, p, decodes + (size_t)f * FT8O_K_MAX_MESSAGES, n_results + f);
+        else n_results[f] = -1;
+        free(mag_power);
+    }
+    (void)nthreads;
+    return 0;
+}
+
 /* Batch forms of the two halves of the path, for the FFT-divergence study (tools/fft_parity.py) and the
  * configs[1] bench leg (GPU waterfall + sync, LDPC on the host cores): the waterfall of B frames with the
  * float32 R4DIF FFT or the float64 DFT, and everything after the waterfall (rtlsdr_ft8d.c:1438-1523). */
@@ -1102,7 +1213,8 @@ void ft8o_waterfall_batch(const float *iq, int B, uint8_t *mag, int f64, int nth
 #endif
     for (int f = 0; f < B; f++) {
         const float *I = iq + (size_t)f * 2 * FT8O_NSAMPLES;
-        if (f64) ft8o_waterfall_f64(I, I + FT8O_NSAMPLES, mag + (size_t)f * FT8O_MAG_ARRAY);
+        if (f64 == 2) (void)ft8o_waterfall_fftw(I, I + FT8O_NSAMPLES, mag + (size_t)f * FT8O_MAG_ARRAY);      /* the reference's FFTW (when bound) */
+        else if (f64) ft8o_waterfall_f64(I, I + FT8O_NSAMPLES, mag + (size_t)f * FT8O_MAG_ARRAY);
         else ft8o_waterfall(I, I + FT8O_NSAMPLES, mag + (size_t)f * FT8O_MAG_ARRAY);
     }
     (void)nthreads;

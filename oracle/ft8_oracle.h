@@ -128,6 +128,13 @@ uint8_t ft8o_quantise_x86(float mag2);                      /* the same as the r
 void ft8o_set_quantiser_x86(int on);                        /* ft8o_quantise / ft8o_waterfall follow the x86 form (default: fenced) */
 void ft8o_waterfall(const float *iSamples, const float *qSamples, uint8_t *mag_power);
 void ft8o_waterfall_f64(const float *iSamples, const float *qSamples, uint8_t *mag_power);
+/* Optional run-time FFTW leg (the reference's own transform: fftwf_plan_dft_1d(NFFT, in, out, FFTW_FORWARD,
+ * FFTW_ESTIMATE) rtlsdr_ft8d.c:326, fftwf_execute :1411), bound with dlopen when libfftw3f.so.3 is installed.
+ * ft8o_fftw_init: 1 = bound (ft8o_fftw_detail() = the library found), 0 = not (detail = the names searched).
+ * explicit_path is tried first (tests); bench.py passes NULL. */
+int  ft8o_fftw_init(const char *explicit_path);
+const char *ft8o_fftw_detail(void);
+int  ft8o_waterfall_fftw(const float *iSamples, const float *qSamples, uint8_t *mag_power);   /* -1: FFTW not bound */
 
 int  ft8o_sync_score(const uint8_t *mag, const ft8o_candidate_t *c);
 int  ft8o_find_sync(const uint8_t *mag, int num_candidates, ft8o_candidate_t *heap, int min_score);
@@ -159,7 +166,9 @@ void ft8o_spots_from_candidates(const uint8_t *mag, const ft8o_candidate_t *cand
                                 const ft8o_params_t *p, struct ft8o_decoder_results *decodes, int32_t *n_results);
 /* batch forms (OpenMP over frames): waterfalls with the float32 R4DIF FFT (f64 = 0) or the float64 DFT (f64 = 1);
  * everything after the waterfall; everything after ft8_find_sync (configs[1]: cands [B][p->max_candidates]) */
-void ft8o_waterfall_batch(const float *iq, int B, uint8_t *mag, int f64, int nthreads);
+void ft8o_waterfall_batch(const float *iq, int B, uint8_t *mag, int f64 /* 0 R4DIF, 1 float64, 2 FFTW (if bound) */, int nthreads);
+int  ft8o_subsystem_batch_fftw(const float *iq, int B, const ft8o_params_t *p,
+                               struct ft8o_decoder_results *decodes, int32_t *n_results, int nthreads);   /* -1: FFTW not bound */
 void ft8o_subsystem_from_waterfall_batch(const uint8_t *mag, int B, const ft8o_params_t *p,
                                          struct ft8o_decoder_results *decodes, int32_t *n_results, int nthreads);
 void ft8o_decode_from_candidates_batch(const uint8_t *mag, const ft8o_candidate_t *cands, const int32_t *counts, int B,

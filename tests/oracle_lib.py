@@ -194,18 +194,49 @@ def subsystem_from_waterfall(mag, params=None):
     return dec, n.value
 
 
-def subsystem_batch(iq, params=None, nthreads=1):
+def subsystem_batch(iq, params=None, nthreads=1, decodes=None):
+    """decodes: the caller's record array as it is BEFORE the call ([B][50], e.g. a byte pattern): the reference writes
+    a slot only for a CQ message and leaves the others as they were (rtlsdr_ft8d.c:1509-1520); None = zeros"""
     iq = np.ascontiguousarray(iq, np.float32)
     B = iq.shape[0]
     assert iq.shape[1:] == (2, NSAMPLES)
-    dec = np.zeros((B, MAX_MESSAGES), RESULT_DTYPE)
+    if decodes is None:
+        dec = np.zeros((B, MAX_MESSAGES), RESULT_DTYPE)
+    else:
+        dec = np.ascontiguousarray(decodes).copy()
+        assert dec.dtype == RESULT_DTYPE and dec.shape == (B, MAX_MESSAGES)
     n = np.zeros(B, np.int32)
     p = params or default_params()
     lib().ft8o_subsystem_batch(_fp(iq), B, C.byref(p), dec.ctypes.data, n.ctypes.data_as(C.POINTER(C.c_int32)), nthreads)
     return dec, n
 
 
+def fftw_init(explicit_path=None):
+    """(bound, detail): binds libfftw3f at run time for the oracle's reference-FFT leg; detail = the library found, or
+    the names searched.  Sticky per process."""
+    L = lib()
+    L.ft8o_fftw_init.argtypes = [C.c_char_p]
+    L.ft8o_fftw_detail.restype = C.c_char_p
+    ok = L.ft8o_fftw_init(None if explicit_path is None else str(explicit_path).encode())
+    return bool(ok), L.ft8o_fftw_detail().decode()
+
+
+def subsystem_batch_fftw(iq, params=None, nthreads=1):
+    """subsystem_batch with the reference's own FFT (needs fftw_init() to have bound the library)"""
+    iq = np.ascontiguousarray(iq, np.float32)
+    B = iq.shape[0]
+    dec = np.zeros((B, MAX_MESSAGES), RESULT_DTYPE)
+    n = np.zeros(B, np.int32)
+    p = params or default_params()
+    L = lib()
+    L.ft8o_subsystem_batch_fftw.argtypes = [C.c_void_p, C.c_int, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_int]
+    if L.ft8o_subsystem_batch_fftw(iq.ctypes.data, B, C.byref(p), dec.ctypes.data, n.ctypes.data, nthreads) != 0:
+        raise RuntimeError("FFTW is not bound: " + L.ft8o_fftw_detail().decode())
+    return dec, n
+
+
 def waterfall_batch(iq, f64=False, nthreads=1):
+    """f64: False = the float32 R4DIF FFT, True = float64 DFT, 2 = the reference's FFTW (after fftw_init bound it)"""
     iq = np.ascontiguousarray(iq, np.float32)
     B = iq.shape[0]
     mag = np.zeros((B, MAG_ARRAY), np.uint8)

@@ -23,12 +23,14 @@ def _host_threads():
     return bench.usable_cores()
 
 
-def _oracle_all(oracle, iq_dev, params=None, chunk=1024):
+def _oracle_all(oracle, iq_dev, params=None, chunk=1024, fill=0):
     """the CPU oracle on EVERY frame of a device batch (OpenMP over frames; D2H in chunks of 393 MB)"""
     decs, ns = [], []
     nt = _host_threads()
     for f0 in range(0, iq_dev.shape[0], chunk):
-        d, n = oracle.subsystem_batch(iq_dev[f0:f0 + chunk].cpu().numpy(), params, nthreads=nt)
+        m = min(chunk, iq_dev.shape[0] - f0)
+        start = None if fill == 0 else np.full((m, 50 * 28), fill, np.uint8).view(oracle.RESULT_DTYPE).reshape(m, 50)
+        d, n = oracle.subsystem_batch(iq_dev[f0:f0 + chunk].cpu().numpy(), params, nthreads=nt, decodes=start)
         decs.append(d)
         ns.append(n)
     return np.concatenate(decs), np.concatenate(ns)
@@ -40,9 +42,10 @@ def _assert_frames_equal(got, got_n, ref, ref_n, what):
     assert not bad, f"{what}: {len(bad)} of {len(ref_n)} frames differ from the oracle, first {bad[:8]}"
 
 
-def _decode_dev(ft8, dec, iq, n):
+def _decode_dev(ft8, dec, iq, n, fill=0):
+    """fill: the byte every record slot holds before the call (the reference leaves non-CQ slots as they were)"""
     import torch
-    spots = torch.zeros((n, ft8.MAX_MESSAGES * 28), dtype=torch.uint8, device="cuda")
+    spots = torch.full((n, ft8.MAX_MESSAGES * 28), fill, dtype=torch.uint8, device="cuda")
     nres = torch.zeros((n,), dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()                 # the fills run on torch's stream, the decoder on its own
     dec.decode_batch_dev(iq, n, spots, nres)
@@ -185,3 +188,69 @@ def test_overlapped_pipeline_at_ragged_batch_sizes(n):
         d2, n2 = _decode_dev(ft8, dec, iq, n)
     assert np.array_equal(n1, n2) and d1.tobytes() == d2.tobytes()
     assert int(n1.sum()) > 4 * n
+
+
+def _cstr(field):
+    """a char[] field as C reads it: up to the first NUL (bytes behind it keep whatever the caller's array held)"""
+    return bytes(field).split(b"\0")[0].decode("latin-1")
+
+
+def _slot_census(d, n, fill):
+    """(messages, written slots, stale slots) over a batch whose records all started as the byte `fill`"""
+    stale_rec = np.full(28, fill, np.uint8).tobytes()
+    msgs = written = stale = 0
+    for f in range(len(n)):
+        k = min(int(n[f]), 50)
+        msgs += int(n[f])
+        for j in range(k):
+            if d[f, j].tobytes() == stale_rec:
+                stale += 1
+            else:
+                written += 1
+    return msgs, written, stale
+
+
+@pytest.mark.parametrize("case", ["configs2", "configs4"])
+def test_mixed_traffic_full_size_vs_oracle(oracle, case):
+    """The traffic a receiver really meets -- about a quarter CQ calls, the rest QSO messages of every type the protocol
+    has, one frame in four with a message heard twice -- through the whole path at configs[2] size (4096 frames, cap 120)
+    and configs[4] size (1024 frames, 60 weak signals, cap 480), EVERY frame against the oracle.  The record arrays start
+    as the byte 0xA5 on both sides: the reference counts every unique message but writes a slot only for a CQ call
+    (rtlsdr_ft8d.c:1509-1520), so most slots below n_results must still hold the caller's bytes, exactly where the
+    oracle leaves them.  (Rounds 1-4 ran these sizes on "CQ call grid" only.)"""
+    import rtlsdr_ft8d_amd as ft8
+    from rtlsdr_ft8d_amd import workload
+    B, S, snr, cap, first = dict(configs2=(4096, 20, (-18.0, 0.0), 120, 200000), configs4=(1024, 60, (-24.0, -14.0), 480, 300000))[case]
+    FILL = 0xA5
+    texts, tones = workload.message_pool(traffic="mixed")
+    with ft8.Decoder(device=0, max_frames=B, max_candidates=cap) as dec:
+        import torch
+        sig, picks = workload.frame_signals(first, B, S, tones, snr_range=snr, dup_fraction=workload.MIXED_DUP_FRACTION)
+        iq = torch.empty((B, 2, ft8.NSAMPLES), dtype=torch.float32, device="cuda")
+        dec.synth_frames(sig, B, S, 1.0, workload.SEED_BASE + 5, iq, first_frame=first)
+        d1, n1 = _decode_dev(ft8, dec, iq, B, fill=FILL)
+        dz, nz = _decode_dev(ft8, dec, iq, B, fill=0)
+        # host-buffer entry with a patterned caller array: the staged copy must carry the caller's bytes in and out
+        hn = 512 + 77
+        start = np.full((hn, 50 * 28), FILL, np.uint8).view(ft8.RESULT_DTYPE).reshape(hn, 50)
+        dh, nh = dec.decode_batch(iq[:hn].cpu().numpy(), decodes=start.copy())
+        rdec, rn = _oracle_all(oracle, iq, oracle.default_params(10, cap, 20), fill=FILL)
+    _assert_frames_equal(d1, n1, rdec, rn, f"mixed traffic, {case}")
+    assert np.array_equal(nh, n1[:hn]) and dh.tobytes() == d1[:hn].tobytes()
+    assert np.array_equal(nz, n1)
+    msgs, written, stale = _slot_census(d1, n1, FILL)
+    # the workload does what it is for: most messages are not CQ calls and leave their slot stale
+    assert msgs > (8 if case == "configs2" else 2) * B and stale > 2 * written > 0, (msgs, written, stale)
+    # the same slots are written whatever the array held before (zeros here), with the same bytes up to each field's NUL
+    for f in range(0, B, 37):
+        for j in range(min(int(n1[f]), 50)):
+            a, z = d1[f, j], dz[f, j]
+            if a.tobytes() != np.full(28, FILL, np.uint8).tobytes():
+                assert (_cstr(a["call"]), _cstr(a["loc"]), a["freq"], a["snr"]) == (_cstr(z["call"]), _cstr(z["loc"]), z["freq"], z["snr"]), (f, j)
+    # every message shape of the pool was decoded somewhere in the batch: what the CQ slots say against what was planted
+    stale_rec = np.full(28, FILL, np.uint8).tobytes()
+    live = [x for f in range(B) for x in d1[f][:min(int(n1[f]), 50)] if x.tobytes() != stale_rec]
+    calls = {_cstr(x["call"]) for x in live}
+    planted_cq_calls = {t.split()[1] for t in texts if t and t.startswith("CQ ")}
+    assert len(calls & planted_cq_calls) >= (0.8 if case == "configs2" else 0.3) * len(planted_cq_calls)
+    assert "(null)" in {_cstr(x["loc"]) for x in live} or case == "configs4"          # "CQ call" without a grid: strtok gives NULL, glibc prints (null)

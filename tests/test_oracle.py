@@ -369,3 +369,86 @@ def test_oracle_against_the_independent_numpy_restatement(oracle):
             checked += 1
             iterated += entered > 0
     assert checked > 150 and iterated > 100          # most candidates really ran message updates
+
+
+def test_mixed_traffic_frame_semantics(oracle):
+    """One frame of the traffic a receiver meets (workload.mixed_message_pool), strong signals, through the oracle's
+    ft8_subsystem: the reference counts EVERY unique message (rtlsdr_ft8d.c:1520) but fills a slot only when the first
+    token starts with "CQ" (:1509-1519), so the slots of QSO messages keep the caller's bytes; a message heard twice is
+    one entry (:1487-1507); "CQ call" without a grid prints "(null)" through %.6s.  These are the semantics the
+    full-size GPU tests compare at 4096 frames; here they are checked against what was planted."""
+    import synth_util as S
+    from rtlsdr_ft8d_amd import workload
+    texts, tones = workload.message_pool(traffic="mixed")
+    want = ["CQ K1EZ DR61", "CQ EA8/OH2XX", "A60XA A64C R+10", "G2A K1EZ -04", "QRP 5W DIPOLE", "CQ YW18FIFA", "CQ EA5GUR", "CQ ZL3EJ"]
+    picks = [texts.index(t) for t in want] + [texts.index("CQ EA8/OH2XX")]          # the last one is heard twice
+    rng = np.random.default_rng(1)
+    fi, fq = rng.normal(0, 1, 48000), rng.normal(0, 1, 48000)
+    for j, k in enumerate(picks):
+        si, sq = S.cpfsk(tones[k], 150 + 140 * j, 1600, S.amplitude_for_snr(-3, 1.0))
+        fi += si
+        fq += sq
+    i32, q32 = fi.astype(np.float32), fq.astype(np.float32)
+    sc = np.float32(0.5) / max(np.abs(i32).max(), np.abs(q32).max())
+    iq = np.stack([i32 * sc, q32 * sc])[None]
+    start = np.full((1, 50 * 28), 0xA5, np.uint8).view(oracle.RESULT_DTYPE).reshape(1, 50)
+    d, n = oracle.subsystem_batch(iq, oracle.default_params(), 1, decodes=start)
+    assert n[0] == len(want)                                               # nine signals, eight unique messages
+    stale = np.full(28, 0xA5, np.uint8).tobytes()
+    cstr = lambda b: bytes(b).split(b"\0")[0].decode("latin-1")
+    live = {(cstr(r["call"]), cstr(r["loc"])) for r in d[0, :n[0]] if r.tobytes() != stale}
+    assert live == {("K1EZ", "DR61"), ("EA8/OH2XX", "(null)"), ("YW18FIFA", "(null)"), ("EA5GUR", "(null)"), ("ZL3EJ", "(null)")}
+    assert sum(r.tobytes() == stale for r in d[0, :n[0]]) == 3             # the three QSO / free-text messages: counted, slot untouched
+    assert all(r.tobytes() == stale for r in d[0, n[0]:])
+    # a written slot keeps the caller's bytes behind each string's NUL (snprintf writes no further)
+    r = next(r for r in d[0, :n[0]] if cstr(r["call"]) == "K1EZ")
+    assert bytes(r["call"])[5:] == b"\xa5" * 8 and bytes(r["loc"])[5:] == b"\xa5" * 2
+
+
+def test_fftw_leg_detects_and_its_plumbing_runs(tmp_path):
+    """The oracle's optional FFTW leg (the reference's own transform, rtlsdr_ft8d.c:326 / :1411, bound with dlopen).
+    In a child process, because the binding is sticky: (a) with no path it reports what it searched or what it found --
+    never an assertion about the box; (b) handed tests/host_fftw_shim (a float64 DFT under FFTW's five names, test-only
+    and labelled as such) by explicit path, every call of the leg executes: init, plan, per-thread buffers, execute,
+    batch form -- and the waterfall agrees with the float64 leg up to threshold flips."""
+    import subprocess
+    import sys
+    shim = str(tmp_path / "libdftshim.so")
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", os.path.join(ROOT, "tests", "host_fftw_shim", "dft_shim.c"), "-lm", "-o", shim])
+    code = r"""
+import sys, json
+sys.path.insert(0, %r)
+import numpy as np
+import oracle_lib as O, synth_util as S
+mode = sys.argv[1]
+ok, detail = O.fftw_init(None if mode == "system" else sys.argv[2])
+out = {"ok": ok, "detail": detail}
+if mode == "shim":
+    enc = S.oracle_encode_fn(O)
+    iq = np.stack([S.make_frame(s, 12, enc)[0] for s in (11, 12, 13, 14)])
+    a = O.waterfall_batch(iq, 2, 2); b = O.waterfall_batch(iq, True, 2); c = O.waterfall_batch(iq, False, 2)
+    out["flips_vs_f64"] = int((a != b).sum()); out["max_step"] = int(np.abs(a.astype(int) - b.astype(int)).max()); out["flips_vs_r4dif"] = int((a != c).sum())
+    d, n = O.subsystem_batch_fftw(iq, None, 2); d0, n0 = O.subsystem_batch(iq, None, 2)
+    out["messages"] = int(n.sum()); out["messages_r4dif"] = int(n0.sum())
+else:
+    try:
+        O.subsystem_batch_fftw(np.zeros((1, 2, 48000), np.float32))
+        out["batch"] = "ran"
+    except RuntimeError as e:
+        out["batch"] = str(e)
+print("RESULT", json.dumps(out))
+""" % os.path.join(ROOT, "tests")
+    def run(*argv):
+        out = subprocess.run([sys.executable, "-c", code] + list(argv), capture_output=True, text=True, timeout=600)
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")]
+        assert out.returncode == 0 and line, out.stdout + out.stderr
+        return json.loads(line[0][7:])
+    r = run("system")
+    if r["ok"]:
+        assert "fftw3f" in r["detail"] and r["batch"] == "ran"
+    else:
+        assert "libfftw3f.so.3" in r["detail"] and "not bound" in r["batch"]      # says where it looked
+    r = run("shim", shim)
+    assert r["ok"] and r["detail"] == shim
+    assert r["max_step"] <= 1 and r["flips_vs_f64"] <= 4 * 94208 // 1000 and r["flips_vs_r4dif"] <= 4 * 94208 // 1000, r
+    assert r["messages"] > 20 and abs(r["messages"] - r["messages_r4dif"]) <= 2, r

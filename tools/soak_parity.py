@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Mass parity run: many batches of on-device synthetic frames with varying density and SNR; every frame's spot
 records from the GPU are compared byte for byte with the CPU oracle (all host cores).
-usage: tools/soak_parity.py [--batches 40] [--frames 4096] [--seed 123]"""
+usage: tools/soak_parity.py [--batches 40] [--frames 4096] [--seed 123] [--traffic cq|mixed]
+--traffic mixed: the message pool of workload.mixed_message_pool (about a quarter CQ calls, the rest QSO traffic of every
+message type, one frame in four with a message heard twice), and every record slot starts as the byte 0xA5 on both sides
+so that the slots the reference leaves untouched (rtlsdr_ft8d.c:1509-1520) are part of the comparison."""
 import argparse, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,6 +16,7 @@ def main():
     ap.add_argument("--batches", type=int, default=40)
     ap.add_argument("--frames", type=int, default=4096)
     ap.add_argument("--seed", type=int, default=123, help="draws the batches' densities, SNR windows and caps, and offsets the frame seeds (123: the run of rounds 2-4)")
+    ap.add_argument("--traffic", choices=("cq", "mixed"), default="cq")
     args = ap.parse_args()
     import torch
     import oracle_lib as O
@@ -22,32 +26,40 @@ def main():
     from bench import usable_cores
     cores = usable_cores()
     B = args.frames
-    _, tones = workload.message_pool()
+    mixed = args.traffic == "mixed"
+    _, tones = workload.message_pool(traffic=args.traffic)
+    fill = 0xA5 if mixed else 0
+    stale_rec = np.full(28, fill, np.uint8).tobytes()
+    start = np.full((B, 1400), fill, np.uint8).view(O.RESULT_DTYPE).reshape(B, 50) if mixed else None
     rng = np.random.default_rng(args.seed)
     dec = ft8.Decoder(device=0, max_frames=B)
     iq = torch.empty((B, 2, ft8.NSAMPLES), dtype=torch.float32, device="cuda")
     spots = torch.zeros((B, 1400), dtype=torch.uint8, device="cuda")
     nres = torch.zeros((B,), dtype=torch.int32, device="cuda")
-    bad = total = msgs = 0
+    bad = total = msgs = written = 0
     t0 = time.time()
     for b in range(args.batches):
         nsig = int(rng.integers(0, 61))
         lo_snr = float(rng.uniform(-26, -10)); hi_snr = lo_snr + float(rng.uniform(2, 20))
         cap = int(rng.choice([120, 120, 120, 60, 240, 480]))
         dec.set_params(max_candidates=cap)
-        sig, _ = workload.frame_signals(1_000_000 + (args.seed - 123) * 10_000_000 + b * B, B, nsig, tones, snr_range=(lo_snr, hi_snr))
+        sig, _ = workload.frame_signals(1_000_000 + (args.seed - 123) * 10_000_000 + b * B, B, nsig, tones, snr_range=(lo_snr, hi_snr),
+                                        dup_fraction=workload.MIXED_DUP_FRACTION if mixed else 0.0)
         dec.synth_frames(sig, B, nsig, 1.0, 777 + b + (args.seed - 123) * 100_003, iq)
-        spots.zero_()
+        spots.fill_(fill)
         torch.cuda.synchronize()                     # the fill runs on torch's stream, the decoder on its own
         dec.decode_batch_dev(iq, B, spots, nres)
         dec.synchronize()
         g = spots.cpu().numpy().view(ft8.RESULT_DTYPE).reshape(B, 50)
         gn = nres.cpu().numpy()
-        rdec, rn = O.subsystem_batch(iq.cpu().numpy(), O.default_params(10, cap, 20), cores)
+        rdec, rn = O.subsystem_batch(iq.cpu().numpy(), O.default_params(10, cap, 20), cores, decodes=start)
         mism = [k for k in range(B) if gn[k] != rn[k] or g[k].tobytes() != rdec[k].tobytes()]
-        bad += len(mism); total += B; msgs += int(gn.sum())
-        print(f"batch {b}: nsig {nsig} snr [{lo_snr:.0f},{hi_snr:.0f}] cap {cap}: {int(gn.sum())} messages, mismatching frames {len(mism)}", flush=True)
-    print(json.dumps({"frames": total, "messages": msgs, "mismatching_frames": bad, "seconds": round(time.time() - t0, 1), "seed": args.seed, "batches": args.batches}))
+        w = int(sum(1 for k in range(B) for j in range(min(int(gn[k]), 50)) if g[k, j].tobytes() != stale_rec)) if mixed else int(np.minimum(gn, 50).sum())
+        bad += len(mism); total += B; msgs += int(gn.sum()); written += w
+        print(f"batch {b}: nsig {nsig} snr [{lo_snr:.0f},{hi_snr:.0f}] cap {cap}: {int(gn.sum())} messages, {w} CQ spots, mismatching frames {len(mism)}", flush=True)
+    print(json.dumps({"frames": total, "messages": msgs, "cq_spots_written": written, "mismatching_frames": bad, "seconds": round(time.time() - t0, 1), "seed": args.seed,
+                      "batches": args.batches, "traffic": args.traffic, "initial_record_byte": fill, "messages_per_frame": round(msgs / max(total, 1), 3),
+                      "cq_spots_per_frame": round(written / max(total, 1), 3), "build_id": ft8.check_build_id()}))
 
 
 if __name__ == "__main__":
