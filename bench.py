@@ -91,7 +91,11 @@ def parse_args(argv=None):
                     help="create the decoder context AFTER the process group and a handful of framework streams (round 3 lost 0.27 ms per step "
                          "that way: streams shared hardware queues; the context now measures co-execution and re-rolls its side streams)")
     ap.add_argument("--debug-flags", type=int, default=0,
-                    help="FT8GPU_DBG_* bits for the decoder context (profiling of the non-product kernel forms; reported in the line, 0 = product)")
+                    help="FT8GPU_DBG_* bits for the decoder context (reported in the line, 0 = product); the kernel-form selectors 8 / 16 / 32 "
+                         "need --ab-lib")
+    ap.add_argument("--ab-lib", action="store_true",
+                    help="run on the A/B build libft8gpu_ab.so (product kernels + the alternative kernel forms; `make -C rtlsdr_ft8d_amd/csrc ab`): "
+                         "profiling of the non-product forms only, reported in the line")
     ap.add_argument("--shards", type=int, default=8, help="configs[3] on one GPU: number of contexts / shards")
     ap.add_argument("--traffic", choices=("cq", "mixed"), default="cq",
                     help="message pool of the synthetic frames: cq = 'CQ call grid' only (SURVEY.md 8(d), the headline); mixed = what a receiver "
@@ -308,7 +312,11 @@ def main():
     out["build_id"] = ft8.check_build_id()
 
     def make_decoder():
-        d = ft8.Decoder(device=local_rank, max_frames=B, min_score=10, max_candidates=maxc, ldpc_iters=20)
+        lib = None
+        if args.ab_lib:
+            lib = ft8.load_ab_library()
+            out["library"] = "libft8gpu_ab.so (A/B build: not the shipped library) " + ft8.build_id(lib)
+        d = ft8.Decoder(device=local_rank, max_frames=B, min_score=10, max_candidates=maxc, ldpc_iters=20, lib=lib)
         if args.debug_flags:
             d.set_debug_flags(args.debug_flags)
             out["debug_flags"] = args.debug_flags           # not the product configuration
@@ -403,6 +411,11 @@ def main():
         for i in range(args.steps):
             step()
             step_ev[i + 1].record(stream)   # per-step spread: decode kernels of step i (the exchange runs on RCCL's stream)
+        if use_dist:
+            # where a multi-rank step's time goes: this rank's kernels are done at t_kernels; whatever the fence still
+            # waits for after that is the exposed tail of the last gathers plus the skew between the ranks (the barrier)
+            stream.synchronize()
+            t_kernels = time.perf_counter() - t0
         fence()
         elapsed = time.perf_counter() - t0
     stage_avg = dec.timings()        # mean over the timed steps (ring of the last 32)
@@ -411,10 +424,28 @@ def main():
     spots, nres = exch.buffers(state["k"] - 1) if state["k"] > 0 else (spots, nres)    # the last step's local records
     per_step = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
 
+    my_elapsed = elapsed
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
+    if use_dist:
+        # per-rank view of the same timed region (one small all-gather, after the clock): which rank is slow, whether its
+        # context runs the overlapped pipeline, how long its own kernels took and what the gather drain + barrier added
+        mine = torch.tensor([my_elapsed, t_kernels, my_elapsed - t_kernels, 1.0 if out.get("overlap") else 0.0, float(np.median(per_step))],
+                            dtype=torch.float64, device=dev)
+        every = torch.empty(world * mine.numel(), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(every, mine)
+        every = every.view(world, -1).cpu().numpy()
+        ms = 1e3 * every[:, 0] / args.steps
+        out["ranks_detail"] = {
+            "ms_per_step": [round(float(v), 4) for v in ms], "ms_per_step_min": round(float(ms.min()), 4), "ms_per_step_max": round(float(ms.max()), 4),
+            "imbalance": round(float(ms.max() / ms.min() - 1.0), 5),
+            "kernels_done_ms_per_step": [round(1e3 * float(v) / args.steps, 4) for v in every[:, 1]],
+            "exposed_gather_drain_and_barrier_ms_total": [round(1e3 * float(v), 4) for v in every[:, 2]],
+            "overlap": [bool(v) for v in every[:, 3]], "median_step_kernels_ms": [round(float(v), 4) for v in every[:, 4]],
+            "note": "per rank, same timed region: wall per step; host time until the rank's own kernels were done; what the final fence (gather "
+                    "drain + barrier) added once, after them; ft8gpu_overlap_active of the rank's context; median hipEvent step time"}
 
     out["value"] = round(total * args.steps / elapsed, 1)
     out["ms_per_step"] = round(1e3 * elapsed / args.steps, 3)
@@ -459,6 +490,7 @@ def main():
             "binding_resource": "valu-issue" if valu_bound else None,
             "valu_busy_frac_pmc": pmc.get("valu_busy"), "valu_frac_of_fp32_peak_pmc": pmc.get("valu_frac"),
             "kernel_hbm_GBps_from_traffic": pmc.get("kernel_hbm_GBps"), "pmc_from": pmc.get("pmc_from"),
+            "pmc_pipeline_form": pmc.get("pmc_pipeline_form"),
             "frac_of_measured_copy_peak": round(achieved / HBM_COPY_PEAK_GBPS, 5),
             "kernel_ms": round(dom_ms, 4), "kernel_launches_per_step": launches,
             "kernel_ms_per_launch": round(dom_ms / launches, 4), "algorithmic_bytes_per_launch": BYTES_PER_FRAME * B // launches,
@@ -627,11 +659,16 @@ def pmc_figures(kernel, frames, launches, ms_per_launch, config=2):
     entries of configs[1] and configs[4] sit under "config1" / "config4").  They describe the kernel sources they were
     collected on: the summary carries a hash of csrc/ and the figures are reported only while it matches the tree this
     bench runs from (and the launch size); otherwise null."""
-    none = {"traffic": None, "valu_busy": None, "valu_frac": None, "kernel_hbm_GBps": None, "pmc_from": None}
+    none = {"traffic": None, "valu_busy": None, "valu_frac": None, "kernel_hbm_GBps": None, "pmc_from": None, "pmc_pipeline_form": None}
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             t = json.load(f)
     except (OSError, ValueError):
+        return none
+    # Per-frame figures carry over between the plain and the two-part pipeline only for the kernels that are the SAME code
+    # in both: the heap replay is not (wave-per-frame kernel in the counted plain run, lane-per-frame kernel for part B of the
+    # product run), so it gets no counter figures here.
+    if kernel not in ("waterfall", "sync", "decode", "spots"):
         return none
     sect = t if config == 2 else t.get(f"config{config}", {})
     e = sect.get(kernel, {})
@@ -646,7 +683,8 @@ def pmc_figures(kernel, frames, launches, ms_per_launch, config=2):
             "valu_frac": round(insts * per_launch * 64 / (ms_per_launch * 1e-3) / FP32_VALU_PEAK, 4) if insts else None,
             "kernel_hbm_GBps": round(traffic / (ms_per_launch * 1e-3) / 1e9, 1),
             "pmc_from": f"profiles/pmc_traffic.json{'' if config == 2 else ' [config%d]' % config} @ csrc {t.get('csrc_sha')}"
-                        f" (per-frame counters of {e.get('frames_per_launch')}-frame launches x {per_launch} frames)"}
+                        f" (per-frame counters of {e.get('frames_per_launch')}-frame launches of the {t.get('pipeline_form', 'plain')} pipeline x {per_launch} frames)",
+            "pmc_pipeline_form": t.get("pipeline_form", "plain")}
 
 
 def usable_cores():

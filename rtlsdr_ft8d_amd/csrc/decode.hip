@@ -523,6 +523,9 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
     }
     if (min_errors == 0) {                                            // wave-uniform
         const uint32_t crc_extracted = (uint32_t)(w1 >> 37) & 0x3FFFu;   // bits 77..90
+        // lane 0 now rewrites dwords other lanes have just stored (1, 5, and the text behind them): order the two across the
+        // wave explicitly instead of leaning on a wave's LDS instructions issuing in program order (converged candidates only)
+        wave_lds_sync();
         if (lane == 0) {
             rec32[1] = crc_extracted | (crc_calc << 16);
             if (crc_extracted == crc_calc) {

@@ -198,15 +198,25 @@ class SpotExchange:
     next step's kernels are enqueued behind it without waiting: the collective (5.7 MB per rank and
     step at 4096 frames) runs under the next batch's decode.  A buffer is waited for just before it is
     reused, and `wait_all()` drains everything (bench.py calls it inside the timed region).
+    Ragged jobs: with `total_frames` the shards are those of shard_range(total_frames, r, world) -- sizes that differ by
+    one frame when the total does not divide -- every rank's segment is padded to the largest shard so that the
+    collective stays ONE equal-sized all-gather, and `gathered()` drops the padding.
     Works on RCCL (device tensors) and on gloo (CPU tensors, tests/test_dist_gloo.py)."""
 
     RECORD_BYTES = 1400
 
-    def __init__(self, frames, world_size, device, collective=None):
+    def __init__(self, frames, world_size, device, collective=None, total_frames=None):
         import torch
         self.frames, self.world = frames, world_size
         self.collective = (world_size > 1) if collective is None else collective     # True forces it for one rank too
-        seg = frames * (self.RECORD_BYTES + 4)
+        if total_frames is None:
+            self.sizes = [frames] * world_size
+        else:
+            self.sizes = [hi - lo for lo, hi in (shard_range(total_frames, r, world_size) for r in range(world_size))]
+            if frames not in self.sizes:
+                raise ValueError(f"{frames} frames is not a shard of {total_frames} frames over {world_size} ranks ({self.sizes})")
+        self.cap = max(self.sizes)                       # frames per segment of the exchange
+        seg = self.cap * (self.RECORD_BYTES + 4)
         self._local = [torch.zeros(seg, dtype=torch.uint8, device=device) for _ in range(2)]
         self._all = [torch.zeros(seg * world_size, dtype=torch.uint8, device=device) for _ in range(2)] if self.collective else None
         self._work = [None, None]
@@ -218,8 +228,8 @@ class SpotExchange:
             self._work[i].wait()
             self._work[i] = None
         flat = self._local[i]
-        n = self.frames * self.RECORD_BYTES
-        return flat[:n].view(self.frames, self.RECORD_BYTES), flat[n:].view(dtype=__import__("torch").int32)
+        n = self.cap * self.RECORD_BYTES
+        return flat[:self.frames * self.RECORD_BYTES].view(self.frames, self.RECORD_BYTES), flat[n:n + 4 * self.frames].view(dtype=__import__("torch").int32)
 
     def launch(self, k):
         import torch.distributed as dist
@@ -234,18 +244,22 @@ class SpotExchange:
                 self._work[i] = None
 
     def gathered(self, k):
-        """(all_spots [world*frames, 1400], all_counts [world*frames]) of step k in global frame order (copies)"""
+        """(all_spots [sum of shards, 1400], all_counts [sum of shards]) of step k in global frame order (copies)"""
         import torch
         i = k & 1
         if self._work[i] is not None:
             self._work[i].wait()
             self._work[i] = None
+        n = self.cap * self.RECORD_BYTES
         if not self.collective:
-            s, c = self._local[i][:self.frames * self.RECORD_BYTES], self._local[i][self.frames * self.RECORD_BYTES:]
+            s, c = self._local[i][:self.frames * self.RECORD_BYTES], self._local[i][n:n + 4 * self.frames]
             return s.view(self.frames, self.RECORD_BYTES).clone(), c.view(dtype=torch.int32).clone()
         seg = self._all[i].view(self.world, -1)
-        n = self.frames * self.RECORD_BYTES
         # copies: the receive buffer is overwritten by the exchange of step k + 2
-        spots = seg[:, :n].reshape(self.world * self.frames, self.RECORD_BYTES).clone()
-        counts = seg[:, n:].clone(memory_format=torch.contiguous_format).view(dtype=torch.int32).reshape(-1)
+        if len(set(self.sizes)) == 1:
+            spots = seg[:, :n].reshape(self.world * self.cap, self.RECORD_BYTES).clone()
+            counts = seg[:, n:].clone(memory_format=torch.contiguous_format).view(dtype=torch.int32).reshape(-1)
+            return spots, counts
+        spots = torch.cat([seg[r, :m * self.RECORD_BYTES].view(m, self.RECORD_BYTES) for r, m in enumerate(self.sizes)])
+        counts = torch.cat([seg[r, n:n + 4 * m].clone().view(dtype=torch.int32) for r, m in enumerate(self.sizes)])
         return spots, counts

@@ -1,5 +1,5 @@
-"""world_size-2 CPU test (gloo) of the multi-GPU plumbing: contiguous frame shards, seeding that
-is independent of the world size, and the single all-gather of the spot records.  The data path
+"""world_size-2 / -3 / -4 CPU tests (gloo) of the multi-GPU plumbing: contiguous frame shards (also ragged ones), seeding
+that is independent of the world size, and the single all-gather of the spot records.  The data path
 itself has no collective (frames are independent); on the GPU box the same code runs on RCCL."""
 import os
 import socket
@@ -60,6 +60,67 @@ def _worker(rank, world, port, total, q):
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, ok, lo, hi))
+
+
+def _worker_ragged(rank, world, port, total, q):
+    try:
+        _worker_ragged_body(rank, world, port, total, q)
+    except Exception as e:                       # a dead rank must fail the test at once, not after the queue's timeout
+        q.put((rank, repr(e), -1, -1))
+        raise
+
+
+def _worker_ragged_body(rank, world, port, total, q):
+    """the real SpotExchange on a job whose frames do not divide by the ranks: shards of unequal size, one equal-sized
+    padded all-gather, padding dropped on the way out; several steps so that both buffers are reused"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rtlsdr_ft8d_amd import workload
+    lo, hi = workload.shard_range(total, rank, world)
+    spots, counts = _fake_spots(lo, hi)
+    ref_spots, ref_counts = _fake_spots(0, total)
+    ex = workload.SpotExchange(hi - lo, world, "cpu", total_frames=total)
+    ok = ex.cap == -(-total // world)
+    for k in range(5):
+        s_buf, c_buf = ex.buffers(k)
+        ok = ok and tuple(s_buf.shape) == (hi - lo, 1400) and tuple(c_buf.shape) == (hi - lo,)
+        s_buf.copy_((spots.to(torch.int32) + k).to(torch.uint8))
+        c_buf.copy_(counts + k)
+        ex.launch(k)
+        if k >= 1:                             # the previous step's list while this one is in flight
+            g_s, g_c = ex.gathered(k - 1)
+            ok = ok and bool(torch.equal(g_s, (ref_spots.to(torch.int32) + k - 1).to(torch.uint8)) and torch.equal(g_c, ref_counts + k - 1))
+    g_s, g_c = ex.gathered(4)
+    ok = ok and bool(torch.equal(g_s, (ref_spots.to(torch.int32) + 4).to(torch.uint8)) and torch.equal(g_c, ref_counts + 4))
+    ex.wait_all()
+    # the per-rank diagnostics bench.py gathers for world > 1: one all-gather of a small float vector per rank
+    mine = torch.tensor([float(rank), 1.0 + 0.5 * rank, float(hi - lo)], dtype=torch.float64)
+    every = torch.empty(world * 3, dtype=torch.float64)           # flat: the form gloo and RCCL both take
+    dist.all_gather_into_tensor(every, mine)
+    every = every.view(world, 3)
+    ok = ok and every[:, 0].tolist() == [float(r) for r in range(world)] and int(every[:, 2].sum().item()) == total
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok, lo, hi))
+
+
+@pytest.mark.parametrize("world,total", [(4, 4 * 37 + 3), (4, 5), (3, 64)])
+def test_spot_exchange_world4_ragged_totals(world, total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ragged, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [True] * world, res
+    assert res[0][2] == 0 and res[-1][3] == total and all(a[3] == b[2] for a, b in zip(res, res[1:]))
+    sizes = [r[3] - r[2] for r in res]
+    assert max(sizes) - min(sizes) <= 1 and (total % world == 0 or len(set(sizes)) == 2)
 
 
 def test_gather_spots_world2():

@@ -51,3 +51,44 @@ def test_committed_counter_evidence_describes_these_kernel_sources():
         import pytest
         pytest.skip(f"profiles/pmc_traffic.json was collected on csrc {t['csrc_sha']}, the tree is {bench.csrc_hash()}: "
                     "re-run TAG=rNN bash tools/gpu_round.sh on a GPU box and copy gpurun_out/profiles_rNN/* to profiles/")
+
+
+def test_hazard_scan_follows_the_control_flow():
+    """the v_cmpx -> DPP scan of tools/kernel_resources.py walks branches (round 4's was a window of the next lines of
+    text): a DPP instruction behind a taken branch is found, enough wait states on EVERY path clear it, and a DPP
+    instruction that only follows in the text -- behind an unconditional branch elsewhere -- is not reported"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources as K
+    asm = """
+kernel:
+  v_cmpx_lt_f32 v1, v2
+  s_cbranch_scc1 .LBB0_2
+  s_nop 4
+  v_add_f32 v1, v2, v3
+.LBB0_1:
+  s_endpgm
+.LBB0_2:
+  s_nop 1
+  v_mov_b32_dpp v1, v2 row_shr:1
+  s_branch .LBB0_1
+"""
+    assert K.cmpx_dpp_hazards(asm) == [(11, "v_mov_b32_dpp v1, v2 row_shr:1")]
+    assert K.cmpx_dpp_hazards(asm.replace("s_nop 1", "s_nop 4")) == []
+    loop = """
+.LBB1_0:
+  v_add_f32_dpp v5, v5, v5 row_shr:1
+  s_nop 0
+  v_cmpx_gt_u32 v0, v1
+  s_cbranch_execnz .LBB1_0
+  s_nop 4
+  v_add_f32_dpp v6, v6, v6 row_shr:2
+"""
+    assert [ln for ln, _ in K.cmpx_dpp_hazards(loop)] == [3]           # the loop's back edge lands on DPP code; the exit path waits
+    skipped = """
+  v_cmpx_lt_f32 v1, v2
+  s_branch .LBB2_9
+  v_mov_b32_dpp v1, v2 row_shr:1
+.LBB2_9:
+  s_endpgm
+"""
+    assert K.cmpx_dpp_hazards(skipped) == []

@@ -3,9 +3,10 @@
 experiment must share a box): the bench batch decoded under different FT8GPU_DBG_* flag sets, interleaved.
   python tools/ab_probe.py [--frames 4096] [--steps 20] [--rounds 3] --arms 0 4
 The arms are sums of the FT8GPU_DBG_* bits of include/ft8gpu.h (1 IEEE division, 2 pipeline form of the stage entry,
-4 one launch per stage); unknown bits are refused by ft8gpu_set_debug_flags.  (The arms 8 / 16 / 24 quoted in
-profiles/r02_ab_kernels.json selected experimental kernels of builds that no longer exist; two BUILDS are compared
-with tools/ab_libs.py.)"""
+4 one launch per stage); unknown bits are refused by ft8gpu_set_debug_flags.  Arms with the kernel-form selectors of
+csrc/ft8gpu_internal.h (8 LDS waterfall, 16 / 32 forced heap forms) run on the A/B build libft8gpu_ab.so (`make ab`), all
+arms of such a run on that one library.  (The arms 8 / 16 / 24 quoted in profiles/r02_ab_kernels.json selected experimental
+kernels of builds that no longer exist; two BUILDS are compared with tools/ab_libs.py.)"""
 import argparse
 import hashlib
 import json
@@ -30,7 +31,9 @@ def main():
     import rtlsdr_ft8d_amd as ft8
     from rtlsdr_ft8d_amd import workload
     B = args.frames
-    dec = ft8.Decoder(device=0, max_frames=B, max_candidates=args.max_candidates)
+    # arms with the kernel-form selector bits (8 LDS waterfall, 16 / 32 forced heap forms) exist in the A/B build only
+    lib = ft8.load_ab_library() if any(a & ~7 for a in args.arms) else None
+    dec = ft8.Decoder(device=0, max_frames=B, max_candidates=args.max_candidates, lib=lib)
     _, tones = workload.message_pool()
     sig, _ = workload.frame_signals(0, B, args.nsig, tones)
     iq = torch.empty((B, 2, ft8.NSAMPLES), dtype=torch.float32, device="cuda")

@@ -4,7 +4,7 @@
 #   prof   rocprofv3 kernel trace + stats  pmc    the four PMC passes (SQ / SQ+GRBM / FETCH_SIZE / WRITE_SIZE) for configs 2, 4 and 1
 # Summaries land in gpurun_out/profiles_$TAG/; copy them to profiles/ to have them judged.  A profiler pass that
 # fails (non-zero exit, or no CSV where one is expected) aborts its stage and leaves profiles/ untouched.
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 STAGES=${STAGES:-"tests bench prof pmc"}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
@@ -67,5 +67,7 @@ if has bench; then
   python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-legs --force-dist > gpurun_out/bench_dist1.log 2>&1; tail -1 gpurun_out/bench_dist1.log > $OUT/${TAG}_bench_rccl_one_rank.json; cut -c1-200 $OUT/${TAG}_bench_rccl_one_rank.json
   python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-legs --force-dist --ctx-last > gpurun_out/bench_dist1_last.log 2>&1; tail -1 gpurun_out/bench_dist1_last.log > $OUT/${TAG}_bench_rccl_one_rank_ctx_last.json; cut -c1-200 $OUT/${TAG}_bench_rccl_one_rank_ctx_last.json
   python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-legs > gpurun_out/bench_plain2.log 2>&1; tail -1 gpurun_out/bench_plain2.log > $OUT/${TAG}_bench_no_dist_same_session.json; cut -c1-200 $OUT/${TAG}_bench_no_dist_same_session.json
+  python bench.py --steps 20 --warmup 5 --traffic mixed --no-host-legs > gpurun_out/bench_mixed.log 2>&1; tail -1 gpurun_out/bench_mixed.log > $OUT/${TAG}_bench_mixed.json; cut -c1-200 $OUT/${TAG}_bench_mixed.json
+  [ -f tools/ab/libft8gpu_r04.so ] && { python tools/ab_libs.py --libs tools/ab/libft8gpu_r04.so rtlsdr_ft8d_amd/libft8gpu.so --rounds 3 > gpurun_out/ab_r04.log 2>&1; tail -1 gpurun_out/ab_r04.log > $OUT/${TAG}_ab_r04_vs_r05.json; cut -c1-300 $OUT/${TAG}_ab_r04_vs_r05.json; }
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-host-legs > gpurun_out/bench_torchrun1.log 2>&1; tail -1 gpurun_out/bench_torchrun1.log | cut -c1-200
 fi

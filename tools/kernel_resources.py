@@ -8,8 +8,9 @@ VGPRs, SGPRs, static LDS bytes, the private (scratch) segment size, the number o
 resident waves per SIMD those numbers allow.  Exit status 1 if
   * any kernel has a scratch segment or a scratch instruction (scratch lines that are written travel to HBM: the
     round-3 LDPC kernel wrote 5.8 x the bytes of its own records that way), or
-  * a DPP instruction follows a v_cmpx (a VALU write of EXEC) within 5 wait states: bp_math.h narrows EXEC inside
-    inline assembly, which the compiler's hazard recogniser cannot see into.
+  * a DPP instruction is reachable from a v_cmpx (a VALU write of EXEC) within 5 wait states, along ANY path of the
+    control flow (branches are followed): bp_math.h narrows EXEC inside inline assembly, which the compiler's hazard
+    recogniser cannot see into.
 tests/test_kernel_resources.py runs this on the CPU box, so neither can come back unnoticed."""
 import argparse
 import concurrent.futures as cf
@@ -53,21 +54,44 @@ def wait_states(line):
 
 
 def cmpx_dpp_hazards(text):
-    """[(line number, text)] of DPP instructions that follow a v_cmpx within 5 wait states (straight-line scan)"""
-    lines = [(i + 1, ln.split(";")[0].strip()) for i, ln in enumerate(text.splitlines())]
-    code = [(i, t) for i, t in lines if t and not t.startswith((".", "_", ";")) and not t.endswith(":")]
-    bad = []
-    for k, (ln, t) in enumerate(code):
+    """[(line number, text)] of DPP instructions reachable from a v_cmpx within 5 wait states.  The walk follows the
+    control flow, not the text: labels are transparent, s_branch continues at its target, s_cbranch_* continues both at
+    its target and behind it (the EXEC-narrowing assembly of bp_math.h sits inside the BP loop, whose back edge and
+    exit lead to code that is nowhere near the next lines of text); s_endpgm / s_setpc end a path."""
+    items, label_at = [], {}
+    for i, raw in enumerate(text.splitlines()):
+        t = raw.split(";")[0].strip()
+        if t.endswith(":"):
+            label_at[t[:-1]] = len(items)              # a label names the next instruction
+            continue
+        if not t or t.startswith((".", ";")):
+            continue
+        if t.startswith("_"):
+            continue
+        items.append((i + 1, t))
+    bad = set()
+    for k, (_, t) in enumerate(items):
         if not t.startswith("v_cmpx"):
             continue
-        waited = 0
-        for ln2, t2 in code[k + 1:k + 8]:
-            if waited >= 5:
-                break
-            if "dpp" in t2 or "row_" in t2 or "quad_perm" in t2:
-                bad.append((ln2, t2))
-            waited += wait_states(t2)
-    return bad
+        stack, seen = [(k + 1, 0)], set()
+        while stack:
+            pos, waited = stack.pop()
+            while pos < len(items) and waited < 5 and (pos, waited) not in seen:
+                seen.add((pos, waited))
+                ln2, t2 = items[pos]
+                if "dpp" in t2 or "row_" in t2 or "quad_perm" in t2:
+                    bad.add((ln2, t2))
+                waited += wait_states(t2)
+                m = re.match(r"(s_branch|s_cbranch_\w+)\s+(\S+)", t2)
+                if m and m.group(2) in label_at:
+                    if m.group(1) == "s_branch":
+                        pos = label_at[m.group(2)]
+                        continue
+                    stack.append((label_at[m.group(2)], waited))
+                elif t2.startswith(("s_endpgm", "s_setpc", "s_swappc")):
+                    break
+                pos += 1
+    return sorted(bad)
 
 
 def kernels_of(text):

@@ -12,7 +12,6 @@ waterfall kernel requests 23 x 2816 x 8 B x 4096 frames = 2.12 GB per launch and
 import argparse
 import collections
 import csv
-import hashlib
 import json
 import os
 
@@ -20,15 +19,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def csrc_hash():
-    """identity of the kernel sources the counters were collected on (bench.py recomputes it and reports the
-    PMC figures only while it matches)"""
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "rtlsdr_ft8d_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")):          # device code and its headers (host-only .c files do not change a kernel)
-            with open(os.path.join(d, name), "rb") as f:
-                h.update(name.encode() + b"\0" + f.read())
-    return h.hexdigest()[:16]
+    """identity of the kernel sources the counters were collected on: the device half of the library's build id
+    (bench.py recomputes it and reports the PMC figures only while it matches)"""
+    import sys
+    sys.path.insert(0, ROOT)
+    import rtlsdr_ft8d_amd as ft8
+    return ft8.device_source_id()
 
 KERNELS = ("ft8_decode_kernel", "ft8_waterfall_kernel", "ft8_sync_kernel", "ft8_heap_simt_kernel", "ft8_heap_kernel", "ft8_spots_kernel",
            "ft8_synth_kernel", "ft8_rx_block_kernel")
@@ -76,6 +72,9 @@ def main():
     print(json.dumps(out, indent=1))
     if args.traffic:
         t = {"csrc_sha": csrc_hash(),
+             # which pipeline the counted run took: "plain" = one launch per stage and batch (the profiler serialises
+             # kernels, so the co-execution probe falls back), "two-part" = the product's overlapped form
+             "pipeline_form": "plain" if frames_per_launch >= args.frames else "two-part",
              "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over "
                        f"`{args.command}`, mean per dispatch; tools/gpu_round.sh + tools/pmc_summary.py"}
         for k, v in out.items():

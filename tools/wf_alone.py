@@ -22,7 +22,8 @@ def main():
     import rtlsdr_ft8d_amd as ft8
     from rtlsdr_ft8d_amd import workload
     B = args.frames
-    dec = ft8.Decoder(device=0, max_frames=B)
+    lib = ft8.load_ab_library() if any(a & ~7 for a in args.arms) else None     # form 8 (LDS) lives in the A/B build
+    dec = ft8.Decoder(device=0, max_frames=B, lib=lib)
     _, tones = workload.message_pool()
     sig, _ = workload.frame_signals(0, B, 20, tones)
     iq = torch.empty((B, 2, ft8.NSAMPLES), dtype=torch.float32, device="cuda")
