@@ -251,6 +251,10 @@ def test_mixed_traffic_full_size_vs_oracle(oracle, case):
     stale_rec = np.full(28, FILL, np.uint8).tobytes()
     live = [x for f in range(B) for x in d1[f][:min(int(n1[f]), 50)] if x.tobytes() != stale_rec]
     calls = {_cstr(x["call"]) for x in live}
-    planted_cq_calls = {t.split()[1] for t in texts if t and t.startswith("CQ ")}
+    planted_cq_calls = {t.split()[1] for t in texts if t and t.split()[0].startswith("CQ") and len(t.split()) > 1}   # incl. free text "CQ73 GL"
     assert len(calls & planted_cq_calls) >= (0.8 if case == "configs2" else 0.3) * len(planted_cq_calls)
+    # CRC-14 false decodes stay rare on this traffic too: a written slot names a call that was planted (second token of a
+    # CQ-first text, e.g. "DX" for "CQ DX K1ABC FN42" -- the reference's token logic, not the operator's call)
+    unknown = [c for c in (_cstr(x["call"]) for x in live) if c not in planted_cq_calls]
+    assert len(unknown) <= 1e-3 * len(live) + 2, unknown[:10]
     assert "(null)" in {_cstr(x["loc"]) for x in live} or case == "configs4"          # "CQ call" without a grid: strtok gives NULL, glibc prints (null)

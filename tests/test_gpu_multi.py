@@ -20,11 +20,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _job(ft8, workload, dec, first, n, nsig=20, snr=(-18.0, 0.0)):
+def _job(ft8, workload, dec, first, n, nsig=20, snr=(-18.0, 0.0), traffic="cq"):
     """frames [first, first + n) of THE job (seed SEED_BASE), synthesised in HBM by `dec`"""
     import torch
-    _, tones = workload.message_pool()
-    sig, _ = workload.frame_signals(first, n, nsig, tones, snr_range=snr)
+    _, tones = workload.message_pool(traffic=traffic)
+    sig, _ = workload.frame_signals(first, n, nsig, tones, snr_range=snr, dup_fraction=workload.MIXED_DUP_FRACTION if traffic == "mixed" else 0.0)
     iq = torch.empty((n, 2, ft8.NSAMPLES), dtype=torch.float32, device="cuda")
     dec.synth_frames(sig, n, nsig, 1.0, workload.SEED_BASE, iq, first_frame=first)
     return iq
@@ -197,33 +197,39 @@ def test_two_ranks_share_gpu0_and_match_the_single_process_batch():
 
 
 # ---- configs[3] at its size on one GPU ------------------------------------------------------------
-def test_config4_32768_frames_eight_shards(oracle):
+@pytest.mark.parametrize("traffic", ["cq", "mixed"])
+def test_config4_32768_frames_eight_shards(oracle, traffic):
     """BASELINE configs[3]: 32 768 frames = 8 contiguous shards of 4096.  With one GPU on the box the eight shards
     are eight contexts on GPU 0 (own streams and HBM buffers each; 12.6 GB of IQ resident), decoded through
     ft8gpu_decode_batch_multi_dev (eight host threads, records gathered at their frame offsets), and must be
     byte-identical to ONE 4096-frame context walking the same 32 768 frames chunk by chunk; the oracle agrees on
-    every one of the 32 768 frames; about 12 messages decode per frame."""
+    every one of the 32 768 frames; about 12 messages decode per frame.
+    traffic = "mixed": the same job on on-air style traffic, with the caller's record array starting as the byte 0xA5
+    (the multi entry carries the caller's bytes to the GPUs and back: slots of non-CQ messages must come home untouched)."""
     import torch
     import rtlsdr_ft8d_amd as ft8
     from rtlsdr_ft8d_amd import workload
     S, B = 8, 4096
     total = S * B
+    fill = 0xA5 if traffic == "mixed" else 0
+    first = 0 if traffic == "cq" else 400000
     decs = [ft8.Decoder(device=0, max_frames=B) for _ in range(S)]
     try:
         shards = []
         for g in range(S):
             lo, hi = workload.shard_range(total, g, S)
             assert (lo, hi) == (g * B, (g + 1) * B)
-            shards.append(_job(ft8, workload, decs[g], lo, B))
-        got, got_n = ft8.decode_batch_multi_dev(decs, shards, [B] * S)
-        again, again_n = ft8.decode_batch_multi_dev(decs, shards, [B] * S, decodes=np.zeros_like(got))
+            shards.append(_job(ft8, workload, decs[g], first + lo, B, traffic=traffic))
+        start = np.full((total, 1400), fill, np.uint8).view(ft8.RESULT_DTYPE).reshape(total, 50)
+        got, got_n = ft8.decode_batch_multi_dev(decs, shards, [B] * S, decodes=start.copy())
+        again, again_n = ft8.decode_batch_multi_dev(decs, shards, [B] * S, decodes=start.copy())
         assert np.array_equal(again_n, got_n) and again.tobytes() == got.tobytes()          # deterministic under 8-way concurrency
         # one context, chunk by chunk, device-resident records
         spots = torch.zeros((B, 1400), dtype=torch.uint8, device="cuda")
         nres = torch.zeros((B,), dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
         for g in range(S):
-            spots.zero_()
+            spots.fill_(fill)
             torch.cuda.synchronize()
             decs[0].decode_batch_dev(shards[g], B, spots, nres)
             decs[0].synchronize()
@@ -231,14 +237,20 @@ def test_config4_32768_frames_eight_shards(oracle):
             assert spots.cpu().numpy().tobytes() == got[g * B:(g + 1) * B].tobytes(), f"shard {g}: records"
         per_frame = float(got_n.mean())
         assert 11.0 < per_frame < 13.5, per_frame
+        if traffic == "mixed":
+            stale = np.full(28, fill, np.uint8).tobytes()
+            used = [got[f, j].tobytes() for f in range(0, total, 16) for j in range(min(int(got_n[f]), 50))]
+            frac_cq = 1.0 - sum(u == stale for u in used) / len(used)
+            assert 0.12 < frac_cq < 0.35, frac_cq           # about 22 % of the pool are CQ calls: the rest leave their slot stale
         # the oracle on ALL 32 768 frames (round 3: 32 frames; about 13 s of the box's 16 usable host cores), shard by
         # shard in 1024-frame chunks so that the host copy stays at 393 MB
         import bench
         nt = bench.usable_cores()
         bad = []
+        chunk_start = None if fill == 0 else np.full((1024, 1400), fill, np.uint8).view(oracle.RESULT_DTYPE).reshape(1024, 50)
         for g in range(S):
             for k0 in range(0, B, 1024):
-                rdec, rn = oracle.subsystem_batch(shards[g][k0:k0 + 1024].cpu().numpy(), nthreads=nt)
+                rdec, rn = oracle.subsystem_batch(shards[g][k0:k0 + 1024].cpu().numpy(), nthreads=nt, decodes=chunk_start)
                 f0 = g * B + k0
                 for j in range(1024):
                     if got_n[f0 + j] != rn[j] or got[f0 + j].tobytes() != rdec[j].tobytes():

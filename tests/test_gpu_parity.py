@@ -42,6 +42,25 @@ def frames(oracle):
     out.append(("fullscale", rng.uniform(-0.5, 0.5, (2, 48000)).astype(np.float32)))
     out.append(("tiny", (rng.normal(0, 1e-9, (2, 48000))).astype(np.float32)))
     out.append(("huge", (rng.normal(0, 50.0, (2, 48000))).astype(np.float32)))
+    # two frames of on-air style traffic (workload.mixed_message_pool: reports, RR73 / RRR / 73, bare calls, R grid, /R /P,
+    # hashed calls, type 4, free text, telemetry, payloads unpack77 refuses), one message heard twice in each: every stage
+    # test below -- waterfall, scores, candidate lists, per-candidate status AND TEXT at 1 / 7 / 20 / 50 iterations, spot
+    # records -- also runs on messages that are not CQ calls and come out of noise
+    from rtlsdr_ft8d_amd import workload
+    texts, tones = workload.message_pool(traffic="mixed")
+    for seed, nsig, snr in [(17, 20, (-16, 0)), (18, 45, (-20, -4))]:
+        r2 = np.random.default_rng(seed)
+        fi, fq = r2.normal(0, 1, 48000), r2.normal(0, 1, 48000)
+        picks = list(r2.integers(0, len(texts), nsig))
+        picks.append(picks[0])
+        for k in picks:
+            si, sq = S.cpfsk(tones[k], r2.uniform(100, 1500), int(round(r2.uniform(0, 1.8) * 3200)), S.amplitude_for_snr(r2.uniform(*snr), 1.0))
+            fi += si
+            fq += sq
+        i32, q32 = fi.astype(np.float32), fq.astype(np.float32)
+        sc = np.float32(0.5) / max(np.abs(i32).max(), np.abs(q32).max())
+        out.append((f"mixed{seed}", np.stack([i32 * sc, q32 * sc]).astype(np.float32)))
+    assert len(out) == 16                              # the gpu_decoder fixture holds 16 frames
     return out
 
 
@@ -154,12 +173,17 @@ def test_decode_candidates_exact(oracle, gpu_decoder, frames, oracle_mags, iters
             counts[k] = len(ref)
         st = gpu_decoder.decode_candidates(oracle_mags, cands, counts)
         nconv = 0
+        texts = set()
         for k in range(B):
             ref = _oracle_status(oracle, oracle_mags[k], cands[k, :counts[k]], iters)
             _compare_status(frames[k][0], st[k], ref)
             nconv += sum(r["ok"] for r in ref)
+            texts |= {r["text"] for r in ref if r["ok"]}
         if iters >= 20:
             assert nconv > 20          # the comparison exercised real decodes
+            # ... of messages that are not CQ calls, out of noise (the mixed-traffic frames): reports, acknowledgements, hashed calls
+            other = {t for t in texts if not t.startswith("CQ")}
+            assert len(other) >= 15 and any(" R-" in t or " R+" in t for t in other) and any(t.rstrip().endswith("73") for t in other), sorted(other)[:40]
     finally:
         gpu_decoder.set_params(ldpc_iters=20)
 

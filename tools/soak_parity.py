@@ -25,6 +25,7 @@ def main():
     sys.path.insert(0, ROOT)
     from bench import usable_cores
     cores = usable_cores()
+    build_id = ft8.check_build_id()               # a stale or foreign library is refused before anything is measured
     B = args.frames
     mixed = args.traffic == "mixed"
     _, tones = workload.message_pool(traffic=args.traffic)
@@ -59,7 +60,7 @@ def main():
         print(f"batch {b}: nsig {nsig} snr [{lo_snr:.0f},{hi_snr:.0f}] cap {cap}: {int(gn.sum())} messages, {w} CQ spots, mismatching frames {len(mism)}", flush=True)
     print(json.dumps({"frames": total, "messages": msgs, "cq_spots_written": written, "mismatching_frames": bad, "seconds": round(time.time() - t0, 1), "seed": args.seed,
                       "batches": args.batches, "traffic": args.traffic, "initial_record_byte": fill, "messages_per_frame": round(msgs / max(total, 1), 3),
-                      "cq_spots_per_frame": round(written / max(total, 1), 3), "build_id": ft8.check_build_id()}))
+                      "cq_spots_per_frame": round(written / max(total, 1), 3), "build_id": build_id}))
 
 
 if __name__ == "__main__":
