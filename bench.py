@@ -526,12 +526,14 @@ def run_config3_one_gpu(args, out, B, nsig, snr, maxc, dev):
     from rtlsdr_ft8d_amd import workload
     S = args.shards
     total = S * B
-    _, pool_tones = workload.message_pool()
+    _, pool_tones = workload.message_pool(traffic=args.traffic)
+    out["config"]["traffic"] = args.traffic
     decs, iqs = [], []
     for g in range(S):
         d = ft8.Decoder(device=dev.index, max_frames=B, min_score=10, max_candidates=maxc, ldpc_iters=20)
         lo, hi = workload.shard_range(total, g, S)
-        sig, _ = workload.frame_signals(lo, B, nsig, pool_tones, snr_range=snr)
+        sig, _ = workload.frame_signals(lo, B, nsig, pool_tones, snr_range=snr,
+                                        dup_fraction=workload.MIXED_DUP_FRACTION if args.traffic == "mixed" else 0.0)
         iq = torch.empty((B, 2, ft8.NSAMPLES), dtype=torch.float32, device=dev)
         d.synth_frames(sig, B, nsig, 1.0, workload.SEED_BASE, iq, first_frame=lo)
         decs.append(d)

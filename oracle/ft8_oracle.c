@@ -1071,6 +1071,47 @@ int ft8o_decode(const uint8_t *mag, const ft8o_candidate_t *cand, ft8o_message_t
     return 1;
 }
 
+/* ft8_decode() for every candidate of B frames, as 48-byte records in the canonical form the product's stage entry
+ * ft8gpu_decode_candidates writes (include/ft8gpu.h: ft8gpu_decode_status): a field is zero unless ft8_lib's ft8_decode
+ * would have set it -- CRCs only when ldpc_errors == 0, unpack_status / ok only when the CRCs match, text only when ok.
+ * Records beyond counts[f] are zero.  Lets a test compare EVERY candidate of a batch -- also the messages that are not
+ * CQ calls, whose text never shows in the spot records -- byte for byte (OpenMP over frames). */
+void ft8o_decode_candidates_batch(const uint8_t *mag, const ft8o_candidate_t *cands, const int32_t *counts, int B, int cap,
+                                  int max_iterations, uint8_t *records /* [B][cap][48] */, int nthreads) {
+    ft8o_init();
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+#endif
+    for (int f = 0; f < B; f++) {
+        uint8_t *rec = records + (size_t)f * cap * 48;
+        memset(rec, 0, (size_t)cap * 48);
+        const int n = counts[f] < cap ? counts[f] : cap;
+        for (int c = 0; c < n; c++, rec += 48) {
+            ft8o_message_t m;
+            ft8o_decode_status_t st;
+            ft8o_decode_extra_t ex;
+            memset(&m, 0, sizeof m);
+            memset(&st, 0, sizeof st);
+            const int ok = ft8o_decode(mag + (size_t)f * FT8O_MAG_ARRAY, &cands[(size_t)f * cap + c], &m, max_iterations, &st, &ex);
+            const int16_t e16 = (int16_t)st.ldpc_errors, i16 = (int16_t)ex.iters;
+            memcpy(rec + 0, &e16, 2);
+            memcpy(rec + 2, &i16, 2);
+            memcpy(rec + 10, ex.a91, 12);
+            if (st.ldpc_errors == 0) {
+                memcpy(rec + 4, &st.crc_extracted, 2);
+                memcpy(rec + 6, &st.crc_calculated, 2);
+                if (st.crc_extracted == st.crc_calculated) {
+                    rec[8] = (uint8_t)(int8_t)st.unpack_status;
+                    rec[9] = ok ? 1 : 0;
+                    if (ok) memcpy(rec + 22, m.text, strnlen(m.text, 25));
+                }
+            }
+        }
+    }
+    (void)nthreads;
+}
+
 /* ------------------------------------------------------------------------------------------
  * ft8_subsystem()  rtlsdr_ft8d.c:1387-1524
  *

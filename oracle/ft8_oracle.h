@@ -152,6 +152,9 @@ int  ft8o_pack77(const char *msg, uint8_t *c77);
 void ft8o_encode(const uint8_t *payload, uint8_t *tones);
 int  ft8o_decode(const uint8_t *mag, const ft8o_candidate_t *cand, ft8o_message_t *message,
                  int max_iterations, ft8o_decode_status_t *status, ft8o_decode_extra_t *extra);
+/* ft8o_decode for every candidate of B frames as canonical 48-byte records (layout of ft8gpu_decode_status) */
+void ft8o_decode_candidates_batch(const uint8_t *mag, const ft8o_candidate_t *cands, const int32_t *counts, int B, int cap,
+                                  int max_iterations, uint8_t *records, int nthreads);
 
 /* rtlsdr_ft8d.c:1387-1524; _ex takes the three compile-time constants as run-time parameters */
 void ft8o_subsystem(const float *iSamples, const float *qSamples, uint32_t samples_len,

@@ -410,6 +410,10 @@ class Decoder:
         """cands_dev: [nframes][max_candidates] 8-byte records, counts_dev: [nframes] int32 (all in HBM)"""
         self._ck(self.lib.ft8gpu_find_sync(self.h, _ptr(mag_dev), nframes, _ptr(cands_dev), _ptr(counts_dev), DEVICE_PTRS))
 
+    def decode_candidates_dev(self, mag_dev, cands_dev, counts_dev, nframes, status_dev):
+        """status_dev: [nframes][max_candidates] 48-byte records in HBM; only records below counts are written"""
+        self._ck(self.lib.ft8gpu_decode_candidates(self.h, _ptr(mag_dev), _ptr(cands_dev), _ptr(counts_dev), nframes, _ptr(status_dev), DEVICE_PTRS))
+
     def waterfall_dev(self, iq_dev, nframes, mag_dev):
         self._ck(self.lib.ft8gpu_waterfall(self.h, _ptr(iq_dev), nframes, _ptr(mag_dev), DEVICE_PTRS))
 

@@ -91,7 +91,43 @@ def main():
     json.dump({"generator": "tests/synth_util.make_frame", "frames": frames},
               open(os.path.join(HERE, "frames.json"), "w"), indent=1)
     print("golden written:", [f["n_results"] for f in frames])
+    mixed_golden()
     report_golden()
+
+
+def slots(dec, n, stale):
+    """the first n record slots as the caller sees them: [call, loc, freq, snr], or "stale" where the reference wrote nothing"""
+    cstr = lambda b: bytes(b).split(b"\0")[0].decode("latin-1")
+    return ["stale" if d.tobytes() == stale else [cstr(d["call"]), cstr(d["loc"]), int(d["freq"]), int(d["snr"])] for d in dec[:n]]
+
+
+def mixed_golden():
+    """mixed.json: two frames of on-air style traffic (messages that are not CQ calls, duplicates) through the oracle, with the
+    record array starting as the byte 0xA5 so that the slots the reference leaves untouched (rtlsdr_ft8d.c:1509-1520) are in the
+    fixture.  The message pool comes from the product's packer (host C, no GPU): rtlsdr_ft8d_amd.workload.mixed_message_pool."""
+    O.build()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from rtlsdr_ft8d_amd import workload
+    texts, tones = workload.message_pool(traffic="mixed")
+    stale = np.full(28, 0xA5, np.uint8).tobytes()
+    frames = []
+    for seed, nsig, snr in [(17, 20, (-16, 0)), (18, 45, (-20, -4))]:
+        iq, planted = S.make_mixed_frame(seed, nsig, snr, texts, tones)
+        mag = O.waterfall(iq[0], iq[1])
+        c = O.find_sync(mag)
+        st = [O.decode(mag, c[k:k + 1]) for k in range(len(c))]
+        start = np.full((1, 50 * 28), 0xA5, np.uint8).view(O.RESULT_DTYPE).reshape(1, 50)
+        dec, n = O.subsystem_batch(iq[None], O.default_params(), 1, decodes=start)
+        frames.append({
+            "seed": seed, "nsig": nsig, "snr_range": list(snr), "planted": planted,
+            "iq_sha256": sha(iq), "waterfall_sha256": sha(mag), "candidates": cand_list(c),
+            "decode": [[s["ldpc_errors"], s["iters"], s["a91"].hex(), s["crc_extracted"] if s["ldpc_errors"] == 0 else None,
+                        s["unpack_status"] if s["ldpc_errors"] == 0 and s["crc_extracted"] == s["crc_calculated"] else None, s["text"]] for s in st],
+            "initial_record_byte": 0xA5, "n_results": int(n[0]), "slots": slots(dec[0], int(n[0]), stale),
+        })
+    json.dump({"generator": "tests/synth_util.make_mixed_frame over workload.mixed_message_pool()", "pool_sha256": sha(tones), "frames": frames},
+              open(os.path.join(HERE, "mixed.json"), "w"), indent=1)
+    print("mixed golden written:", [(f["n_results"], sum(s != "stale" for s in f["slots"])) for f in frames])
 
 
 def report_golden():
@@ -127,5 +163,7 @@ def report_golden():
 if __name__ == "__main__":
     if sys.argv[1:] == ["report"]:
         report_golden()
+    elif sys.argv[1:] == ["mixed"]:
+        mixed_golden()
     else:
         main()

@@ -276,6 +276,22 @@ def decode_from_candidates_batch(mag, cands, counts, params=None, nthreads=1):
     return dec, n
 
 
+def decode_candidates_batch(mag, cands, counts, iters=20, nthreads=1):
+    """ft8_decode (rtlsdr_ft8d.c:1476) for every candidate of B frames -> uint8 [B][cap][48]: the canonical status records
+    ft8gpu_decode_candidates writes (fields zero unless ft8_decode would have set them)"""
+    mag = np.ascontiguousarray(mag, np.uint8).reshape(-1, MAG_ARRAY)
+    B = mag.shape[0]
+    cands = np.ascontiguousarray(cands)
+    counts = np.ascontiguousarray(counts, np.int32)
+    assert cands.dtype == CAND_DTYPE and cands.shape[0] == B
+    cap = cands.shape[1]
+    out = np.zeros((B, cap, 48), np.uint8)
+    L = lib()
+    L.ft8o_decode_candidates_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.ft8o_decode_candidates_batch(mag.ctypes.data, cands.ctypes.data, counts.ctypes.data, B, cap, iters, out.ctypes.data, nthreads)
+    return out
+
+
 def synth_cpfsk(tones, f_tone0_hz, start_sample, amplitude):
     """rtlsdr_ft8d.c:946-955 generalised to S signals, no noise: (i, q) float32 [48000] each"""
     tones = np.ascontiguousarray(tones, np.uint8).reshape(-1, 79)

@@ -63,6 +63,25 @@ def make_frame(seed, nsig, encode_fn, snr_range=(-18.0, 0.0), noise_sigma=1.0, c
     return iq, msgs
 
 
+def make_mixed_frame(seed, nsig, snr_range, texts, tones, noise_sigma=1.0):
+    """a frame of on-air style traffic: nsig messages drawn from a pool (rtlsdr_ft8d_amd.workload.mixed_message_pool:
+    texts / tones) plus the first one again at another frequency (one message heard twice), in AWGN, peak-normalised
+    to 0.5.  Returns (iq float32 [2][48000], list of planted texts; None = a payload unpack77 refuses)."""
+    rng = np.random.default_rng(seed)
+    fi, fq = rng.normal(0.0, noise_sigma, NSAMPLES), rng.normal(0.0, noise_sigma, NSAMPLES)
+    picks = list(rng.integers(0, len(texts), nsig))
+    if picks:
+        picks.append(picks[0])
+    for k in picks:
+        si, sq = cpfsk(tones[k], rng.uniform(100.0, 1500.0), int(round(rng.uniform(0.0, 1.8) * 3200)),
+                       amplitude_for_snr(rng.uniform(*snr_range), noise_sigma))
+        fi += si
+        fq += sq
+    i32, q32 = fi.astype(np.float32), fq.astype(np.float32)
+    scale = np.float32(0.5) / max(np.abs(i32).max(), np.abs(q32).max(), np.float32(1e-24))
+    return np.stack([i32 * scale, q32 * scale]).astype(np.float32), [texts[k] for k in picks]
+
+
 def oracle_encode_fn(oracle):
     def enc(msg):
         rc, p = oracle.pack77(msg)

@@ -258,3 +258,93 @@ def test_mixed_traffic_full_size_vs_oracle(oracle, case):
     unknown = [c for c in (_cstr(x["call"]) for x in live) if c not in planted_cq_calls]
     assert len(unknown) <= 1e-3 * len(live) + 2, unknown[:10]
     assert "(null)" in {_cstr(x["loc"]) for x in live} or case == "configs4"          # "CQ call" without a grid: strtok gives NULL, glibc prints (null)
+
+
+def _message_kind(text):
+    """coarse type of a decoded message text (what unpack77 branch produced it)"""
+    import re
+    t = text.rstrip(" ")
+    tok = t.split(" ")
+    if re.fullmatch(r"[0-9A-F]{18}", t):
+        return "telemetry"
+    if "<...>" in tok:
+        return "hashed"
+    if tok[0] == "CQ" and len(tok) >= 3 and re.fullmatch(r"[A-Z]{1,4}|[0-9]{3}", tok[1]) and len(tok) == 4:
+        return "cq_modifier"
+    if tok[0] == "CQ":
+        return "cq_nogrid" if len(tok) == 2 else "cq"
+    if len(tok) == 2 and text.endswith(" "):
+        return "two_calls"
+    if len(tok) == 4 and tok[2] == "R":
+        return "r_grid"
+    if len(tok) == 3 and tok[2] in ("RRR", "RR73", "73"):
+        return tok[2]
+    if len(tok) == 3 and re.fullmatch(r"R[+-][0-9]{2}", tok[2]):
+        return "r_report"
+    if len(tok) == 3 and re.fullmatch(r"[+-][0-9]{2}", tok[2]):
+        return "report"
+    if len(tok) == 3 and re.fullmatch(r"[A-R]{2}[0-9]{2}", tok[2]):
+        return "suffix" if "/R" in t or "/P" in t else "grid"
+    return "free_text"
+
+
+def test_mixed_traffic_every_candidate_record_vs_oracle(oracle):
+    """What the spot records cannot show: a message that is not a CQ call leaves no text in the output -- it is counted and
+    de-duplicated, nothing more -- so a wrong character in a decoded report or acknowledgement would pass every whole-path
+    comparison unless it happened to change the dedup.  Here EVERY candidate of 1024 mixed-traffic frames (about 117 000) goes
+    through the stage entry ft8gpu_decode_candidates and its 48-byte status record -- parity errors, iterations entered, packed
+    bits, both CRCs, unpack status, ok and the TEXT -- is compared byte for byte with ft8_decode of the oracle on the same
+    waterfall and candidate; then again with the form of the LDPC kernel the batch pipeline runs (everything but the error
+    count).  Every message shape of the pool must have been decoded out of noise somewhere in the batch."""
+    import collections
+    import torch
+    import rtlsdr_ft8d_amd as ft8
+    from rtlsdr_ft8d_amd import workload
+    B, S, cap = 1024, 20, 120
+    texts, tones = workload.message_pool(traffic="mixed")
+    with ft8.Decoder(device=0, max_frames=B, max_candidates=cap) as dec:
+        sig, _ = workload.frame_signals(500000, B, S, tones, snr_range=(-18.0, 0.0), dup_fraction=workload.MIXED_DUP_FRACTION)
+        iq = torch.empty((B, 2, ft8.NSAMPLES), dtype=torch.float32, device="cuda")
+        dec.synth_frames(sig, B, S, 1.0, workload.SEED_BASE + 9, iq, first_frame=500000)
+        mag = torch.empty((B, ft8.MAG_ARRAY), dtype=torch.uint8, device="cuda")
+        cands = torch.zeros((B, cap, 8), dtype=torch.uint8, device="cuda")
+        counts = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        status = torch.zeros((B, cap, 48), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        dec.waterfall_dev(iq, B, mag)
+        dec.find_sync_dev(mag, B, cands, counts)
+        dec.decode_candidates_dev(mag, cands, counts, B, status)
+        dec.synchronize()
+        g_full = status.cpu().numpy()
+        dec.set_debug_flags(ft8.DBG_PIPELINE_FORM)
+        status.zero_()
+        torch.cuda.synchronize()
+        dec.decode_candidates_dev(mag, cands, counts, B, status)
+        dec.synchronize()
+        g_pipe = status.cpu().numpy()
+        dec.set_debug_flags(0)
+    h_mag, h_counts = mag.cpu().numpy(), counts.cpu().numpy()
+    h_cands = cands.cpu().numpy().view(oracle.CAND_DTYPE).reshape(B, cap)
+    for f in range(0, B, 64):                                    # the inputs of the comparison are the oracle's own on a sample
+        ref = oracle.find_sync(h_mag[f], cap, 10)
+        assert h_counts[f] == len(ref) and np.array_equal(h_cands[f, :len(ref)], ref)
+    want = oracle.decode_candidates_batch(h_mag, h_cands, h_counts, 20, _host_threads())
+    bad = np.flatnonzero((g_full != want).any(axis=2))
+    assert bad.size == 0, f"{bad.size} of {int(h_counts.sum())} candidate records differ from the oracle, first (frame, candidate) {divmod(int(bad[0]), cap)}"
+    # the pipeline form: ldpc_errors is 0 or 83 there, every other byte is the same
+    w2, g2 = want.copy(), g_pipe.copy()
+    assert set(np.unique(g2[:, :, 0:2].view(np.int16))) <= {0, 83}
+    conv = want[:, :, 0:2].view(np.int16)[..., 0] == 0
+    assert np.array_equal(g2[:, :, 0:2].view(np.int16)[..., 0] == 0, conv)
+    w2[:, :, 0:2] = 0
+    g2[:, :, 0:2] = 0
+    assert np.array_equal(g2, w2)
+    st = want.reshape(-1, 48).view(ft8.STATUS_DTYPE).reshape(B, cap)
+    ok = st["ok"] == 1
+    kinds = collections.Counter(_message_kind(t.decode()) for t in st["text"][ok])
+    assert int(ok.sum()) > 12 * B, int(ok.sum())
+    need = {"cq", "cq_modifier", "cq_nogrid", "grid", "report", "r_report", "RR73", "RRR", "73", "two_calls", "r_grid", "suffix", "hashed", "free_text", "telemetry"}
+    assert need <= set(kinds), (sorted(need - set(kinds)), kinds)
+    # codewords of a type unpack77 has no branch for: LDPC and CRC pass, unpack fails, ft8_decode returns false
+    refused = (st["ldpc_errors"] == 0) & (st["crc_extracted"] == st["crc_calculated"]) & (st["unpack_status"] < 0) & (np.arange(cap)[None, :] < h_counts[:, None])
+    assert int(refused.sum()) >= 5 and not st["ok"][refused].any()

@@ -49,17 +49,7 @@ def frames(oracle):
     from rtlsdr_ft8d_amd import workload
     texts, tones = workload.message_pool(traffic="mixed")
     for seed, nsig, snr in [(17, 20, (-16, 0)), (18, 45, (-20, -4))]:
-        r2 = np.random.default_rng(seed)
-        fi, fq = r2.normal(0, 1, 48000), r2.normal(0, 1, 48000)
-        picks = list(r2.integers(0, len(texts), nsig))
-        picks.append(picks[0])
-        for k in picks:
-            si, sq = S.cpfsk(tones[k], r2.uniform(100, 1500), int(round(r2.uniform(0, 1.8) * 3200)), S.amplitude_for_snr(r2.uniform(*snr), 1.0))
-            fi += si
-            fq += sq
-        i32, q32 = fi.astype(np.float32), fq.astype(np.float32)
-        sc = np.float32(0.5) / max(np.abs(i32).max(), np.abs(q32).max())
-        out.append((f"mixed{seed}", np.stack([i32 * sc, q32 * sc]).astype(np.float32)))
+        out.append((f"mixed{seed}", S.make_mixed_frame(seed, nsig, snr, texts, tones)[0]))
     assert len(out) == 16                              # the gpu_decoder fixture holds 16 frames
     return out
 

@@ -452,3 +452,42 @@ print("RESULT", json.dumps(out))
     assert r["ok"] and r["detail"] == shim
     assert r["max_step"] <= 1 and r["flips_vs_f64"] <= 4 * 94208 // 1000 and r["flips_vs_r4dif"] <= 4 * 94208 // 1000, r
     assert r["messages"] > 20 and abs(r["messages"] - r["messages_r4dif"]) <= 2, r
+
+
+def test_golden_mixed_traffic_frames(oracle):
+    """tests/golden/mixed.json: two frames of on-air style traffic frozen stage by stage -- candidate list, per-candidate
+    outcome and TEXT (reports, acknowledgements, bare calls with their trailing blank, hashed calls, free text), and the
+    record slots as the caller sees them when the array started as 0xA5: "stale" where the reference writes nothing
+    (rtlsdr_ft8d.c:1509-1520).  The GPU stage tests run the same two frames (tests/test_gpu_parity.py: frames fixture)."""
+    from rtlsdr_ft8d_amd import workload
+    g = load("mixed.json")
+    texts, tones = workload.message_pool(traffic="mixed")
+    assert sha(tones) == g["pool_sha256"], "the mixed message pool changed: regenerate golden (make_golden.py mixed)"
+    stale = np.full(28, 0xA5, np.uint8).tobytes()
+    cstr = lambda b: bytes(b).split(b"\0")[0].decode("latin-1")
+    for fr in g["frames"]:
+        iq, planted = S.make_mixed_frame(fr["seed"], fr["nsig"], tuple(fr["snr_range"]), texts, tones)
+        assert planted == fr["planted"] and sha(iq) == fr["iq_sha256"]
+        mag = oracle.waterfall(iq[0], iq[1])
+        assert sha(mag) == fr["waterfall_sha256"]
+        c = oracle.find_sync(mag)
+        assert cand_list(c) == fr["candidates"]
+        for k, exp in enumerate(fr["decode"]):
+            s = oracle.decode(mag, c[k:k + 1])
+            got = [s["ldpc_errors"], s["iters"], s["a91"].hex(), s["crc_extracted"] if s["ldpc_errors"] == 0 else None,
+                   s["unpack_status"] if s["ldpc_errors"] == 0 and s["crc_extracted"] == s["crc_calculated"] else None, s["text"]]
+            assert got == exp, (fr["seed"], k)
+        start = np.full((1, 50 * 28), 0xA5, np.uint8).view(oracle.RESULT_DTYPE).reshape(1, 50)
+        dec, n = oracle.subsystem_batch(iq[None], oracle.default_params(), 1, decodes=start)
+        slots = ["stale" if d.tobytes() == stale else [cstr(d["call"]), cstr(d["loc"]), int(d["freq"]), int(d["snr"])] for d in dec[0, :n[0]]]
+        assert int(n[0]) == fr["n_results"] and slots == fr["slots"]
+        # what was planted explains what came out: every decoded text is a planted one, duplicates collapse to one entry
+        decoded = {x[5] for x in fr["decode"] if x[5]}
+        assert decoded <= {oracle.unpack77(ft8_pack(t))[1] for t in planted if t is not None}
+        assert fr["n_results"] == len(decoded)
+        assert all(d.tobytes() == stale for d in dec[0, n[0]:])
+
+
+def ft8_pack(text):
+    import rtlsdr_ft8d_amd as ft8
+    return ft8.pack77(text).tobytes()

@@ -17,6 +17,9 @@ def main():
     ap.add_argument("--frames", type=int, default=4096)
     ap.add_argument("--seed", type=int, default=123, help="draws the batches' densities, SNR windows and caps, and offsets the frame seeds (123: the run of rounds 2-4)")
     ap.add_argument("--traffic", choices=("cq", "mixed"), default="cq")
+    ap.add_argument("--records", action="store_true",
+                    help="also compare the 48-byte status record of EVERY candidate (parity errors, iterations, packed bits, CRCs, unpack status, "
+                         "text) through the stage entries: the text of a message that is not a CQ call never reaches the spot records")
     args = ap.parse_args()
     import torch
     import oracle_lib as O
@@ -38,6 +41,10 @@ def main():
     spots = torch.zeros((B, 1400), dtype=torch.uint8, device="cuda")
     nres = torch.zeros((B,), dtype=torch.int32, device="cuda")
     bad = total = msgs = written = 0
+    rec_bad = rec_total = rec_ok = 0
+    if args.records:
+        mag = torch.empty((B, ft8.MAG_ARRAY), dtype=torch.uint8, device="cuda")
+        counts = torch.zeros((B,), dtype=torch.int32, device="cuda")
     t0 = time.time()
     for b in range(args.batches):
         nsig = int(rng.integers(0, 61))
@@ -55,12 +62,29 @@ def main():
         gn = nres.cpu().numpy()
         rdec, rn = O.subsystem_batch(iq.cpu().numpy(), O.default_params(10, cap, 20), cores, decodes=start)
         mism = [k for k in range(B) if gn[k] != rn[k] or g[k].tobytes() != rdec[k].tobytes()]
+        if args.records:
+            st_c = torch.zeros((B, cap, 48), dtype=torch.uint8, device="cuda")       # [B][cap] records and candidates for this batch's cap
+            cd_c = torch.zeros((B, cap, 8), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            dec.waterfall_dev(iq, B, mag)
+            dec.find_sync_dev(mag, B, cd_c, counts)
+            dec.decode_candidates_dev(mag, cd_c, counts, B, st_c)
+            dec.synchronize()
+            h_counts = counts.cpu().numpy()
+            want = O.decode_candidates_batch(mag.cpu().numpy(), cd_c.cpu().numpy().view(O.CAND_DTYPE).reshape(B, cap), h_counts, 20, cores)
+            got = st_c.cpu().numpy()
+            rb = int((got != want).any(axis=2).sum())
+            rec_bad += rb; rec_total += int(h_counts.sum()); rec_ok += int((want[:, :, 9] == 1).sum())
+            del st_c, cd_c
+            if rb:
+                print(f"batch {b}: {rb} candidate records differ", flush=True)
         w = int(sum(1 for k in range(B) for j in range(min(int(gn[k]), 50)) if g[k, j].tobytes() != stale_rec)) if mixed else int(np.minimum(gn, 50).sum())
         bad += len(mism); total += B; msgs += int(gn.sum()); written += w
         print(f"batch {b}: nsig {nsig} snr [{lo_snr:.0f},{hi_snr:.0f}] cap {cap}: {int(gn.sum())} messages, {w} CQ spots, mismatching frames {len(mism)}", flush=True)
     print(json.dumps({"frames": total, "messages": msgs, "cq_spots_written": written, "mismatching_frames": bad, "seconds": round(time.time() - t0, 1), "seed": args.seed,
                       "batches": args.batches, "traffic": args.traffic, "initial_record_byte": fill, "messages_per_frame": round(msgs / max(total, 1), 3),
-                      "cq_spots_per_frame": round(written / max(total, 1), 3), "build_id": build_id}))
+                      "cq_spots_per_frame": round(written / max(total, 1), 3), "build_id": build_id,
+                      **({"candidate_records_compared": rec_total, "candidate_records_decoded_ok": rec_ok, "candidate_records_differing": rec_bad} if args.records else {})}))
 
 
 if __name__ == "__main__":
