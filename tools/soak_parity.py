@@ -17,6 +17,10 @@ def main():
     ap.add_argument("--frames", type=int, default=4096)
     ap.add_argument("--seed", type=int, default=123, help="draws the batches' densities, SNR windows and caps, and offsets the frame seeds (123: the run of rounds 2-4)")
     ap.add_argument("--traffic", choices=("cq", "mixed"), default="cq")
+    ap.add_argument("--edges", action="store_true",
+                    help="signals all over the edges of the search window: tone 0 between -20 and 1620 Hz (bins 0 and 255, aliasing above "
+                         "1600 Hz) and start times between -1.5 and +3.0 s (frames that begin before the window or run out of it): real decodes "
+                         "where the sync score drops terms and the LLR extraction reads blocks that do not exist")
     ap.add_argument("--records", action="store_true",
                     help="also compare the 48-byte status record of EVERY candidate (parity errors, iterations, packed bits, CRCs, unpack status, "
                          "text) through the stage entries: the text of a message that is not a CQ call never reaches the spot records")
@@ -52,7 +56,8 @@ def main():
         cap = int(rng.choice([120, 120, 120, 60, 240, 480]))
         dec.set_params(max_candidates=cap)
         sig, _ = workload.frame_signals(1_000_000 + (args.seed - 123) * 10_000_000 + b * B, B, nsig, tones, snr_range=(lo_snr, hi_snr),
-                                        dup_fraction=workload.MIXED_DUP_FRACTION if mixed else 0.0)
+                                        dup_fraction=workload.MIXED_DUP_FRACTION if mixed else 0.0,
+                                        **(dict(f_range=(-20.0, 1620.0), dt_range=(-1.5, 3.0)) if args.edges else {}))
         dec.synth_frames(sig, B, nsig, 1.0, 777 + b + (args.seed - 123) * 100_003, iq)
         spots.fill_(fill)
         torch.cuda.synchronize()                     # the fill runs on torch's stream, the decoder on its own
@@ -82,7 +87,7 @@ def main():
         bad += len(mism); total += B; msgs += int(gn.sum()); written += w
         print(f"batch {b}: nsig {nsig} snr [{lo_snr:.0f},{hi_snr:.0f}] cap {cap}: {int(gn.sum())} messages, {w} CQ spots, mismatching frames {len(mism)}", flush=True)
     print(json.dumps({"frames": total, "messages": msgs, "cq_spots_written": written, "mismatching_frames": bad, "seconds": round(time.time() - t0, 1), "seed": args.seed,
-                      "batches": args.batches, "traffic": args.traffic, "initial_record_byte": fill, "messages_per_frame": round(msgs / max(total, 1), 3),
+                      "batches": args.batches, "traffic": args.traffic, "edges": bool(args.edges), "initial_record_byte": fill, "messages_per_frame": round(msgs / max(total, 1), 3),
                       "cq_spots_per_frame": round(written / max(total, 1), 3), "build_id": build_id,
                       **({"candidate_records_compared": rec_total, "candidate_records_decoded_ok": rec_ok, "candidate_records_differing": rec_bad} if args.records else {})}))
 
