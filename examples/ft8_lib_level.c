@@ -5,8 +5,10 @@
  * and CQ filter.  With libft8gpu.so behind those symbols this is what the UNMODIFIED rtlsdr_ft8d.c does when
  * it is compiled with -I<repo>/include and linked against libft8gpu.so instead of the ft8_lib objects.
  *
- *   ft8_lib_level           self-test frame ("CQ K1JT FN20QI", as decoderSelfTest() :913-972) plus two more
- *                           signals; result compared with the library's own ft8_subsystem() on the same frame
+ *   ft8_lib_level           self-test frame ("CQ K1JT FN20QI", as decoderSelfTest() :913-972) plus thirteen more signals
+ *                           of every message shape (reports, RR73 twice, bare calls, type 4, hashed call, free text,
+ *                           CQ with a modifier / without a grid); result compared with the library's own
+ *                           ft8_subsystem() on the same frame
  *
  * The waterfall comes from the library's stage entry (the reference computes it with fftw3f, :1395-1435).
  * Build:  gcc -O2 -std=gnu17 -Iinclude examples/ft8_lib_level.c -Lrtlsdr_ft8d_amd -lft8gpu \
@@ -108,6 +110,18 @@ int main(void) {
     add_signal("CQ K1JT FN20QI", 50.0f, 0.5f, 0);
     add_signal("CQ DL1ABC JO62", 700.0f, 0.2f, 1600);
     add_signal("W9XYZ K1ABC EN37", 1211.0f, 0.3f, 800);     /* not a CQ: counted, its slot stays untouched */
+    /* what most of a band looks like: QSO traffic of every shape, one message on two frequencies, CQ calls without a grid */
+    add_signal("K1ABC W9XYZ -11", 150.0f, 0.25f, 400);
+    add_signal("W9XYZ K1ABC R-09", 250.0f, 0.22f, 2000);
+    add_signal("K1ABC W9XYZ RR73", 350.0f, 0.3f, 1200);
+    add_signal("K1ABC W9XYZ RR73", 1450.0f, 0.12f, 2400);    /* the same message again: one entry (rtlsdr_ft8d.c:1487-1507) */
+    add_signal("W9XYZ K1ABC 73", 450.0f, 0.2f, 0);
+    add_signal("G4ABC PA9XYZ", 550.0f, 0.25f, 3000);         /* two bare calls: text with a trailing blank */
+    add_signal("CQ PJ4/K1ABC", 850.0f, 0.3f, 1000);          /* type 4 CQ: no locator token -> "(null)" */
+    add_signal("CQ73 GL", 950.0f, 0.2f, 500);                /* free text whose first token starts with "CQ" */
+    add_signal("<PJ4/K1ABC> W9XYZ RRR", 1050.0f, 0.25f, 1500);
+    add_signal("TNX BOB 73 GL", 1130.0f, 0.2f, 200);
+    add_signal("CQ DX VK3ABC QF22", 1310.0f, 0.3f, 2800);    /* second token is the modifier: call = "DX" */
 
     ft8gpu_ctx *ctx = NULL;
     if (ft8gpu_create(&ctx, 0, 1, NULL) != 0) { fprintf(stderr, "%s\n", ft8gpu_last_error()); return 2; }
@@ -129,8 +143,17 @@ int main(void) {
     for (int k = 0; k < n1; k++)
         if (via_ft8_lib[k].call[0] != 0x5a) printf("  %2d %8d %10.12s %6.6s\n", via_ft8_lib[k].snr, via_ft8_lib[k].freq, via_ft8_lib[k].call, via_ft8_lib[k].loc);
     /* snprintf leaves the bytes behind the terminator alone in both paths, so whole records compare */
-    if (n1 != n2 || n1 < 3 || memcmp(via_ft8_lib, via_subsystem, sizeof via_ft8_lib) != 0) { fprintf(stderr, "MISMATCH\n"); return 1; }
-    if (strcmp(via_ft8_lib[0].call, "K1JT") || strcmp(via_ft8_lib[0].loc, "FN20")) { fprintf(stderr, "K1JT FN20 not in slot 0\n"); return 1; }
+    if (n1 != n2 || n1 < 13 || memcmp(via_ft8_lib, via_subsystem, sizeof via_ft8_lib) != 0) { fprintf(stderr, "MISMATCH\n"); return 1; }
+    int written = 0, null_loc = 0;
+    for (int k = 0; k < n1; k++) {
+        if ((unsigned char)via_ft8_lib[k].call[0] == 0x5a && (unsigned char)via_ft8_lib[k].call[1] == 0x5a) continue;   /* slot left untouched */
+        written++;
+        null_loc += !strcmp(via_ft8_lib[k].loc, "(null)");
+    }
+    if (written < 5 || written > n1 - 6 || null_loc < 2) { fprintf(stderr, "unexpected slot census: %d written of %d, %d without locator\n", written, n1, null_loc); return 1; }
+    int k1jt = 0;                                           /* slots follow the candidates' score order: not necessarily slot 0 here */
+    for (int k = 0; k < n1; k++) k1jt |= !strcmp(via_ft8_lib[k].call, "K1JT") && !strcmp(via_ft8_lib[k].loc, "FN20");
+    if (!k1jt) { fprintf(stderr, "K1JT FN20 not among the spots\n"); return 1; }
     puts("ft8_lib-level path == ft8_subsystem");
     return 0;
 }

@@ -668,6 +668,8 @@ def test_ft8_lib_level_c_caller(tmp_path):
     out = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "ft8_lib-level path == ft8_subsystem" in out.stdout and "K1JT" in out.stdout and "DL1ABC" in out.stdout
+    # the frame carries QSO traffic too: 13 unique messages, five of them CQ-first (two without a locator), one heard twice
+    assert "ft8_lib level: 13 messages, ft8_subsystem: 13 messages" in out.stdout and "PJ4/K1ABC" in out.stdout and "(null)" in out.stdout
 
 
 def test_ft8_lib_level_symbols_match_the_oracle(oracle, frames, oracle_mags):
