@@ -69,7 +69,7 @@ ABI_SYMBOLS = [
     "ft8gpu_synth_frames", "ft8gpu_synth_frames_at", "ft8gpu_rx_decimate", "ft8gpu_pskreporter_datagrams", "ft8gpu_format_spots",
     "ft8gpu_dev_alloc", "ft8gpu_dev_free", "ft8gpu_memcpy_h2d", "ft8gpu_memcpy_d2h", "ft8gpu_host_alloc", "ft8gpu_host_free",
     "ft8gpu_overlap_active", "ft8gpu_overlap_reason", "ft8gpu_build_id", "ft8gpu_pack77",
-    "ft8gpu_set_debug_flags", "ft8gpu_selftest_bp_math", "ft8gpu_gather_spots", "ft8gpu_gather_shutdown",
+    "ft8gpu_set_debug_flags", "ft8gpu_selftest_bp_math", "ft8gpu_selftest_norm_math", "ft8gpu_gather_spots", "ft8gpu_gather_shutdown",
     "ft8gpu_shard_workers", "ft8gpu_decode_batch_multi", "ft8gpu_decode_batch_multi_dev",
     "ft8_find_sync", "ft8_decode", "ft8_encode", "pack77",            # ft8_lib level (include/ft8_lib/ft8/*.h)
     "initFFTW", "freeFFTW", "ft8_subsystem", "ft8gpu_read_raw_iq", "ft8gpu_read_c2", "ft8gpu_write_raw_iq",
@@ -176,6 +176,8 @@ def _declare(L):
     if hasattr(L, "ft8gpu_pack77"):                       # absent from older builds loaded by load_library_at
         L.ft8gpu_pack77.argtypes = [C.c_char_p, vp]
         L.ft8gpu_build_id.restype = C.c_char_p
+    if hasattr(L, "ft8gpu_selftest_norm_math"):
+        L.ft8gpu_selftest_norm_math.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.ft8gpu_overlap_reason.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.ft8gpu_encode.argtypes = [vp, vp]
     L.ft8gpu_encode.restype = None
@@ -329,6 +331,12 @@ class Decoder:
         d = dict(zip(keys, [int(v) for v in out]))
         d["tanh_max"] = float(np.array([d["tanh_max_bits"]], np.uint32).view(np.float32)[0])
         return d
+
+    def selftest_norm_math(self):
+        """sqrtf(24.0f / v), the LLR scale factor, against exact arithmetic for every float v in [2^-60, 2^60]"""
+        out = (C.c_uint64 * 5)()
+        self._ck(self.lib.ft8gpu_selftest_norm_math(self.h, out))
+        return dict(zip(("inputs", "div_bad", "sqrt_bad", "compose_bad", "first_bad"), [int(v) for v in out]))
 
     def enable_timing(self, on=True):
         self._ck(self.lib.ft8gpu_enable_timing(self.h, int(on)))

@@ -156,6 +156,15 @@ __device__ __forceinline__ float atanh_one(float x) {
     return FAST ? div_one_3(a, b) : __fdiv_rn(a, b);
 }
 
+// ---- ftx_normalize_logl's scale factor: sqrtf(24.0f / variance) (ft8_lib decode.c), two correctly rounded IEEE operations.
+// HIP's __fsqrt_rn is NOT that: without OCML_BASIC_ROUNDED_OPERATIONS it is __ocml_native_sqrt_f32, the raw v_sqrt_f32
+// (1 ulp).  Rounds 1-4 used it, and about every hundredth candidate's LLRs came out scaled one ulp low -- invisible in
+// any output until round 5 compared the status record of EVERY candidate of 20 million (a hard decision within an ulp of
+// zero flipped in 93 of them: tools/record_diff_probe.py).  __builtin_sqrtf is the correctly rounded expansion (v_sqrt_f32
+// plus a residual test either side) under the default -fhip-fp32-correctly-rounded-divide-sqrt; bp_selftest.hip checks
+// both operations against exact arithmetic for every float.
+__device__ __forceinline__ float llr_norm_factor(float variance) { return __builtin_sqrtf(__fdiv_rn(24.0f, variance)); }
+
 // domains of the fast forms (what decode.hip's guard establishes; see guard_key there)
 constexpr float kTanhMinAbs = 0x1p-82f;          // x == 0 or |x| >= 2^-82 (any larger |x|: the clamp takes over beyond 4.97)
 constexpr float kAtanhMinAbs = 0x1p-59f;         // P == 0 or |P| >= 2^-59

@@ -65,7 +65,61 @@ __global__ __launch_bounds__(256) void bp_math_exhaustive(Counts *out, uint32_t 
     if (bad) atomicMax(&out->first_bad, bad);
 }
 
+// ---- the LLR scale factor sqrtf(24.0f / variance): both operations against exact arithmetic -------------------------
+// For every positive float v in [2^-60, 2^60]: q = 24.0f / v must be the correctly rounded quotient, s = sqrtf(q) the
+// correctly rounded root, and bpm::llr_norm_factor(v) must be exactly s.  "Correctly rounded" is tested without trusting
+// any other division or root: in double, q * v is exact (48 bits) and so is its distance from 24; (s +- half an ulp)^2 is
+// exact (50 bits).  q is right iff |q v - 24| <= (ulp(q) / 2) v, s iff (s - h)^2 < q < (s + h)^2.
+struct NormCounts { unsigned long long inputs, div_bad, sqrt_bad, compose_bad; unsigned int first_bad; };
+
+__device__ __forceinline__ double half_ulp(float y) {          // half the distance to the next float above |y| (y normal)
+    const int e = (int)((__float_as_uint(y) >> 23) & 0xFF) - 127;
+    return __longlong_as_double((long long)(e - 24 + 1023) << 52);
+}
+
+__global__ __launch_bounds__(256) void norm_math_exhaustive(NormCounts *out, uint32_t first, uint64_t n) {
+    unsigned long long ni = 0, db = 0, sb = 0, cb = 0;
+    unsigned int bad = 0;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t bits = first + (uint32_t)i;
+        const float v = __uint_as_float(bits);
+        if (!(v >= 0x1p-60f && v <= 0x1p60f)) continue;
+        ++ni;
+        const float q = __fdiv_rn(24.0f, v);
+        const float s = __builtin_sqrtf(q);
+        const double r = __builtin_fabs((double)q * (double)v - 24.0);
+        if (r > half_ulp(q) * (double)v) { ++db; bad = bits; }
+        const double h = half_ulp(s), lo = (double)s - h, hi = (double)s + h;
+        if (!(lo * lo < (double)q && (double)q < hi * hi)) { ++sb; bad = bits; }
+        if (__float_as_uint(bpm::llr_norm_factor(v)) != __float_as_uint(s)) { ++cb; bad = bits; }
+    }
+    if (ni) atomicAdd(&out->inputs, ni);
+    if (db) atomicAdd(&out->div_bad, db);
+    if (sb) atomicAdd(&out->sqrt_bad, sb);
+    if (cb) atomicAdd(&out->compose_bad, cb);
+    if (bad) atomicMax(&out->first_bad, bad);
+}
+
 }  // namespace
+
+// out[0..4]: inputs, quotients 24/v not correctly rounded, roots not correctly rounded, llr_norm_factor != sqrtf(24/v), one
+//            offending input (0 = none)
+hipError_t run_norm_math_selftest(uint64_t out[5], hipStream_t s) {
+    NormCounts *d = nullptr, h;
+    hipError_t e = hipMalloc(&d, sizeof(NormCounts));
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(d, 0, sizeof(NormCounts), s);
+    for (uint32_t part = 0; part < 8 && e == hipSuccess; ++part) {          // positive floats only
+        hipLaunchKernelGGL(norm_math_exhaustive, dim3(256 * 32), dim3(256), 0, s, d, part << 28, (uint64_t)1 << 28);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    if (e != hipSuccess) return e;
+    out[0] = h.inputs; out[1] = h.div_bad; out[2] = h.sqrt_bad; out[3] = h.compose_bad; out[4] = h.first_bad;
+    return hipSuccess;
+}
 
 // out[0..6]: tanh inputs, tanh mismatches, atanh inputs, atanh mismatches, packed-form mismatches,
 //            bits of max |fast_tanh|, one offending input (0 = none)

@@ -227,7 +227,7 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
     const float sum2 = (float)wave_sum(isum2);
     const float inv_n = 1.0f / 174;
     const float variance = (sum2 - (sum * sum * inv_n)) * inv_n;
-    const float norm_factor = __fsqrt_rn(__fdiv_rn(24.0f, variance));
+    const float norm_factor = bpm::llr_norm_factor(variance);       // sqrtf(24.0f / variance), both correctly rounded (bp_math.h)
 #pragma unroll
     for (int r = 0; r < 3; ++r) cw[r] = has[r] ? cw[r] * norm_factor : 0.0f;
 

@@ -597,6 +597,20 @@ def test_bp_division_chains_by_exhaustion():
             d.set_debug_flags(16)            # kernel-form selectors exist in the A/B build only
 
 
+def test_llr_scale_factor_is_correctly_rounded_on_every_float():
+    """ftx_normalize_logl scales the soft bits by sqrtf(24.0f / variance): two correctly rounded operations in the reference.
+    Rounds 1-4 computed the root with HIP's __fsqrt_rn, which (without OCML_BASIC_ROUNDED_OPERATIONS) is the raw 1-ulp
+    v_sqrt_f32: about one candidate in a hundred got LLRs one ulp low, visible only where a hard decision sat within an ulp
+    of zero -- 93 candidates in 20 million, found by comparing every candidate's status record (tools/soak_parity.py
+    --records).  ft8gpu_selftest_norm_math holds the quotient and the root the kernel computes against EXACT arithmetic
+    (products and squares that are exact in double) for every float in [2^-60, 2^60]."""
+    import rtlsdr_ft8d_amd as ft8
+    with ft8.Decoder(device=0, max_frames=1) as d:
+        r = d.selftest_norm_math()
+    assert r["inputs"] == 120 * (1 << 23) + 1, r                 # every float of 120 binades and 2^60 itself
+    assert r["div_bad"] == 0 and r["sqrt_bad"] == 0 and r["compose_bad"] == 0 and r["first_bad"] == 0, r
+
+
 def test_decode_pipeline_form_of_the_kernel(oracle):
     """the batch pipeline runs the BP kernel without the exact error count: a scalar group-parity test
     screens every hard decision and only survivors get the exact per-row check.  With
