@@ -1071,6 +1071,21 @@ int ft8o_decode(const uint8_t *mag, const ft8o_candidate_t *cand, ft8o_message_t
     return 1;
 }
 
+/* ft8_find_sync (rtlsdr_ft8d.c:1450) for B waterfalls: candidate lists [B][cap] (zero behind each frame's count) and counts */
+void ft8o_find_sync_batch(const uint8_t *mag, int B, int cap, int min_score, ft8o_candidate_t *cands, int32_t *counts, int nthreads) {
+    ft8o_init();
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+#endif
+    for (int f = 0; f < B; f++) {
+        ft8o_candidate_t *c = cands + (size_t)f * cap;
+        memset(c, 0, sizeof(ft8o_candidate_t) * (size_t)cap);
+        counts[f] = ft8o_find_sync(mag + (size_t)f * FT8O_MAG_ARRAY, cap, c, min_score);
+    }
+    (void)nthreads;
+}
+
 /* ft8_decode() for every candidate of B frames, as 48-byte records in the canonical form the product's stage entry
  * ft8gpu_decode_candidates writes (include/ft8gpu.h: ft8gpu_decode_status): a field is zero unless ft8_lib's ft8_decode
  * would have set it -- CRCs only when ldpc_errors == 0, unpack_status / ok only when the CRCs match, text only when ok.

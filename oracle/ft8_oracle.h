@@ -152,6 +152,8 @@ int  ft8o_pack77(const char *msg, uint8_t *c77);
 void ft8o_encode(const uint8_t *payload, uint8_t *tones);
 int  ft8o_decode(const uint8_t *mag, const ft8o_candidate_t *cand, ft8o_message_t *message,
                  int max_iterations, ft8o_decode_status_t *status, ft8o_decode_extra_t *extra);
+/* ft8o_find_sync for B waterfalls (OpenMP over frames): cands [B][cap], zero behind each count */
+void ft8o_find_sync_batch(const uint8_t *mag, int B, int cap, int min_score, ft8o_candidate_t *cands, int32_t *counts, int nthreads);
 /* ft8o_decode for every candidate of B frames as canonical 48-byte records (layout of ft8gpu_decode_status) */
 void ft8o_decode_candidates_batch(const uint8_t *mag, const ft8o_candidate_t *cands, const int32_t *counts, int B, int cap,
                                   int max_iterations, uint8_t *records, int nthreads);

@@ -276,6 +276,18 @@ def decode_from_candidates_batch(mag, cands, counts, params=None, nthreads=1):
     return dec, n
 
 
+def find_sync_batch(mag, max_candidates=120, min_score=10, nthreads=1):
+    """ft8_find_sync for B waterfalls -> (cands [B][cap] CAND_DTYPE with zeros behind each count, counts [B])"""
+    mag = np.ascontiguousarray(mag, np.uint8).reshape(-1, MAG_ARRAY)
+    B = mag.shape[0]
+    cands = np.zeros((B, max_candidates), CAND_DTYPE)
+    counts = np.zeros(B, np.int32)
+    L = lib()
+    L.ft8o_find_sync_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.ft8o_find_sync_batch(mag.ctypes.data, B, max_candidates, min_score, cands.ctypes.data, counts.ctypes.data, nthreads)
+    return cands, counts
+
+
 def decode_candidates_batch(mag, cands, counts, iters=20, nthreads=1):
     """ft8_decode (rtlsdr_ft8d.c:1476) for every candidate of B frames -> uint8 [B][cap][48]: the canonical status records
     ft8gpu_decode_candidates writes (fields zero unless ft8_decode would have set them)"""

@@ -325,9 +325,11 @@ def test_mixed_traffic_every_candidate_record_vs_oracle(oracle):
         dec.set_debug_flags(0)
     h_mag, h_counts = mag.cpu().numpy(), counts.cpu().numpy()
     h_cands = cands.cpu().numpy().view(oracle.CAND_DTYPE).reshape(B, cap)
-    for f in range(0, B, 64):                                    # the inputs of the comparison are the oracle's own on a sample
-        ref = oracle.find_sync(h_mag[f], cap, 10)
-        assert h_counts[f] == len(ref) and np.array_equal(h_cands[f, :len(ref)], ref)
+    # the two stage boundaries in front of the decode, on EVERY frame: all 94 208 bytes of every waterfall, every ordered candidate list
+    ref_mag = oracle.waterfall_batch(iq.cpu().numpy(), False, _host_threads())
+    assert np.array_equal(h_mag, ref_mag), f"{int((h_mag != ref_mag).sum())} waterfall cells differ"
+    ref_cands, ref_counts = oracle.find_sync_batch(ref_mag, cap, 10, _host_threads())
+    assert np.array_equal(h_counts, ref_counts) and np.array_equal(h_cands.view(np.uint64), ref_cands.view(np.uint64))
     want = oracle.decode_candidates_batch(h_mag, h_cands, h_counts, 20, _host_threads())
     bad = np.flatnonzero((g_full != want).any(axis=2))
     assert bad.size == 0, f"{bad.size} of {int(h_counts.sum())} candidate records differ from the oracle, first (frame, candidate) {divmod(int(bad[0]), cap)}"

@@ -21,9 +21,11 @@ def main():
                     help="signals all over the edges of the search window: tone 0 between -20 and 1620 Hz (bins 0 and 255, aliasing above "
                          "1600 Hz) and start times between -1.5 and +3.0 s (frames that begin before the window or run out of it): real decodes "
                          "where the sync score drops terms and the LLR extraction reads blocks that do not exist")
-    ap.add_argument("--records", action="store_true",
-                    help="also compare the 48-byte status record of EVERY candidate (parity errors, iterations, packed bits, CRCs, unpack status, "
-                         "text) through the stage entries: the text of a message that is not a CQ call never reaches the spot records")
+    ap.add_argument("--records", "--stages", action="store_true", dest="records",
+                    help="also compare every stage boundary of every frame through the stage entries: all 94 208 waterfall bytes, the ordered "
+                         "candidate list, and the 48-byte status record of EVERY candidate (parity errors, iterations, packed bits, CRCs, unpack "
+                         "status, text) -- the text of a message that is not a CQ call never reaches the spot records, and a deviation inside "
+                         "a candidate that does not decode reaches nothing")
     args = ap.parse_args()
     import torch
     import oracle_lib as O
@@ -45,7 +47,7 @@ def main():
     spots = torch.zeros((B, 1400), dtype=torch.uint8, device="cuda")
     nres = torch.zeros((B,), dtype=torch.int32, device="cuda")
     bad = total = msgs = written = 0
-    rec_bad = rec_total = rec_ok = 0
+    rec_bad = rec_total = rec_ok = wf_bad_cells = wf_bad_frames = cand_bad_frames = 0
     if args.records:
         mag = torch.empty((B, ft8.MAG_ARRAY), dtype=torch.uint8, device="cuda")
         counts = torch.zeros((B,), dtype=torch.int32, device="cuda")
@@ -76,7 +78,14 @@ def main():
             dec.decode_candidates_dev(mag, cd_c, counts, B, st_c)
             dec.synchronize()
             h_counts = counts.cpu().numpy()
-            want = O.decode_candidates_batch(mag.cpu().numpy(), cd_c.cpu().numpy().view(O.CAND_DTYPE).reshape(B, cap), h_counts, 20, cores)
+            h_mag = mag.cpu().numpy()
+            h_cands = cd_c.cpu().numpy().view(O.CAND_DTYPE).reshape(B, cap)
+            ref_mag = O.waterfall_batch(iq.cpu().numpy(), False, cores)                       # every byte of every waterfall
+            wdiff = (h_mag != ref_mag)
+            wf_bad_cells += int(wdiff.sum()); wf_bad_frames += int(wdiff.any(axis=1).sum())
+            ref_cands, ref_counts = O.find_sync_batch(ref_mag, cap, 10, cores)                # the ordered candidate lists
+            cand_bad_frames += int(((h_counts != ref_counts) | (h_cands.view(np.uint64) != ref_cands.view(np.uint64)).any(axis=1)).sum())
+            want = O.decode_candidates_batch(h_mag, h_cands, h_counts, 20, cores)
             got = st_c.cpu().numpy()
             rb = int((got != want).any(axis=2).sum())
             rec_bad += rb; rec_total += int(h_counts.sum()); rec_ok += int((want[:, :, 9] == 1).sum())
@@ -89,7 +98,9 @@ def main():
     print(json.dumps({"frames": total, "messages": msgs, "cq_spots_written": written, "mismatching_frames": bad, "seconds": round(time.time() - t0, 1), "seed": args.seed,
                       "batches": args.batches, "traffic": args.traffic, "edges": bool(args.edges), "initial_record_byte": fill, "messages_per_frame": round(msgs / max(total, 1), 3),
                       "cq_spots_per_frame": round(written / max(total, 1), 3), "build_id": build_id,
-                      **({"candidate_records_compared": rec_total, "candidate_records_decoded_ok": rec_ok, "candidate_records_differing": rec_bad} if args.records else {})}))
+                      **({"waterfall_cells_compared": total * ft8.MAG_ARRAY, "waterfall_cells_differing": wf_bad_cells, "waterfall_frames_differing": wf_bad_frames,
+                          "candidate_lists_differing": cand_bad_frames, "candidate_records_compared": rec_total, "candidate_records_decoded_ok": rec_ok,
+                          "candidate_records_differing": rec_bad} if args.records else {})}))
 
 
 if __name__ == "__main__":
