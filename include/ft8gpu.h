@@ -163,9 +163,12 @@ int  ft8gpu_selftest_bp_math(ft8gpu_ctx *ctx, uint64_t out[7]);
 /* The same kind of proof for the scale factor of the soft bits, sqrtf(24.0f / variance) (ftx_normalize_logl of ft8_lib decode.c,
  * reached through ft8_decode, rtlsdr_ft8d.c:1476): for every float v in [2^-60, 2^60] the quotient and the root the LDPC kernel
  * computes are checked against exact arithmetic (products and squares that are exact in double), not against another
- * division or root.  out[0..4] = inputs, quotients not correctly rounded, roots not correctly rounded, kernel function !=
- * sqrtf(24.0f / v), one offending input pattern (0 = none).  (Round 5: HIP's __fsqrt_rn turned out to be the 1-ulp native root.) */
-int  ft8gpu_selftest_norm_math(ft8gpu_ctx *ctx, uint64_t out[5]);
+ * division or root.  The same exact test is applied to the divisions of fast_tanh / fast_atanh themselves on their whole
+ * domains -- the "IEEE quotient" ft8gpu_selftest_bp_math compares the short chains with.  out[0..6] = inputs, quotients 24/v not
+ * correctly rounded, roots not correctly rounded, kernel function != sqrtf(24.0f / v), one offending input pattern (0 = none),
+ * rational-function divisions tested, of those not correctly rounded.  (Round 5: HIP's __fsqrt_rn turned out to be the 1-ulp
+ * native root.) */
+int  ft8gpu_selftest_norm_math(ft8gpu_ctx *ctx, uint64_t out[7]);
 int  ft8gpu_set_params(ft8gpu_ctx *ctx, const ft8gpu_params *params);
 int  ft8gpu_enable_timing(ft8gpu_ctx *ctx, int on);
 int  ft8gpu_get_timings(ft8gpu_ctx *ctx, ft8gpu_timings *out, int32_t *nruns);

@@ -334,9 +334,9 @@ class Decoder:
 
     def selftest_norm_math(self):
         """sqrtf(24.0f / v), the LLR scale factor, against exact arithmetic for every float v in [2^-60, 2^60]"""
-        out = (C.c_uint64 * 5)()
+        out = (C.c_uint64 * 7)()
         self._ck(self.lib.ft8gpu_selftest_norm_math(self.h, out))
-        return dict(zip(("inputs", "div_bad", "sqrt_bad", "compose_bad", "first_bad"), [int(v) for v in out]))
+        return dict(zip(("inputs", "div_bad", "sqrt_bad", "compose_bad", "first_bad", "rational_inputs", "rational_div_bad"), [int(v) for v in out]))
 
     def enable_timing(self, on=True):
         self._ck(self.lib.ft8gpu_enable_timing(self.h, int(on)))

@@ -352,7 +352,7 @@ int ft8gpu_selftest_bp_math(ft8gpu_ctx *c, uint64_t out[7]) {
     return 0;
 }
 
-int ft8gpu_selftest_norm_math(ft8gpu_ctx *c, uint64_t out[5]) {
+int ft8gpu_selftest_norm_math(ft8gpu_ctx *c, uint64_t out[7]) {
     if (!out) return fail("NULL argument");
     CHECK_COMMON(c, 0);
     HIP_TRY(run_norm_math_selftest(out, c->stream));

@@ -70,7 +70,17 @@ __global__ __launch_bounds__(256) void bp_math_exhaustive(Counts *out, uint32_t 
 // correctly rounded root, and bpm::llr_norm_factor(v) must be exactly s.  "Correctly rounded" is tested without trusting
 // any other division or root: in double, q * v is exact (48 bits) and so is its distance from 24; (s +- half an ulp)^2 is
 // exact (50 bits).  q is right iff |q v - 24| <= (ulp(q) / 2) v, s iff (s - h)^2 < q < (s + h)^2.
-struct NormCounts { unsigned long long inputs, div_bad, sqrt_bad, compose_bad; unsigned int first_bad; };
+// And the premise of the proof above it: the exhaustive comparison of bp_math.h's chains is against "the compiler's
+// division" -- which is the IEEE quotient only if THAT is correctly rounded.  Same exact test, for the numerator and
+// denominator of fast_tanh on every x it can see and of fast_atanh on its domain: |q b - a| <= (ulp(q) / 2) |b|.
+struct NormCounts { unsigned long long inputs, div_bad, sqrt_bad, compose_bad, rational_inputs, rational_div_bad; unsigned int first_bad; };
+
+__device__ __forceinline__ bool quotient_is_rounded(float q, float a, float b) {
+    const uint32_t e = (__float_as_uint(q) >> 23) & 0xFF;
+    if (e == 0 || e == 0xFF) return true;                       // zero, subnormal, non-finite quotients: outside this test
+    const double r = __builtin_fabs((double)q * (double)b - (double)a);
+    return r <= __longlong_as_double((long long)((int)e - 127 - 24 + 1023) << 52) * __builtin_fabs((double)b);
+}
 
 __device__ __forceinline__ double half_ulp(float y) {          // half the distance to the next float above |y| (y normal)
     const int e = (int)((__float_as_uint(y) >> 23) & 0xFF) - 127;
@@ -78,11 +88,24 @@ __device__ __forceinline__ double half_ulp(float y) {          // half the dista
 }
 
 __global__ __launch_bounds__(256) void norm_math_exhaustive(NormCounts *out, uint32_t first, uint64_t n) {
-    unsigned long long ni = 0, db = 0, sb = 0, cb = 0;
+    unsigned long long ni = 0, db = 0, sb = 0, cb = 0, ri = 0, rb = 0;
     unsigned int bad = 0;
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t bits = first + (uint32_t)i;
         const float v = __uint_as_float(bits);
+        {   // the two rational functions' own divisions (x = v and x = -v give the same |q|: positive x suffices)
+            const float x = v, x2 = x * x;
+            if (x >= bpm::kTanhMinAbs && x <= 4.97f) {
+                const float a = x * (945.0f + x2 * (105.0f + x2)), b = 945.0f + x2 * (420.0f + x2 * 15.0f);
+                ++ri;
+                if (!quotient_is_rounded(__fdiv_rn(a, b), a, b)) { ++rb; bad = bits; }
+            }
+            if (x >= bpm::kAtanhMinAbs && x <= bpm::kAtanhMaxAbs) {
+                const float a = x * (945.0f + x2 * (-735.0f + x2 * 64.0f)), b = 945.0f + x2 * (-1050.0f + x2 * 225.0f);
+                ++ri;
+                if (!quotient_is_rounded(__fdiv_rn(a, b), a, b)) { ++rb; bad = bits; }
+            }
+        }
         if (!(v >= 0x1p-60f && v <= 0x1p60f)) continue;
         ++ni;
         const float q = __fdiv_rn(24.0f, v);
@@ -97,14 +120,16 @@ __global__ __launch_bounds__(256) void norm_math_exhaustive(NormCounts *out, uin
     if (db) atomicAdd(&out->div_bad, db);
     if (sb) atomicAdd(&out->sqrt_bad, sb);
     if (cb) atomicAdd(&out->compose_bad, cb);
+    if (ri) atomicAdd(&out->rational_inputs, ri);
+    if (rb) atomicAdd(&out->rational_div_bad, rb);
     if (bad) atomicMax(&out->first_bad, bad);
 }
 
 }  // namespace
 
-// out[0..4]: inputs, quotients 24/v not correctly rounded, roots not correctly rounded, llr_norm_factor != sqrtf(24/v), one
-//            offending input (0 = none)
-hipError_t run_norm_math_selftest(uint64_t out[5], hipStream_t s) {
+// out[0..6]: inputs, quotients 24/v not correctly rounded, roots not correctly rounded, llr_norm_factor != sqrtf(24/v), one
+//            offending input (0 = none), divisions of fast_tanh / fast_atanh tested, of those not correctly rounded
+hipError_t run_norm_math_selftest(uint64_t out[7], hipStream_t s) {
     NormCounts *d = nullptr, h;
     hipError_t e = hipMalloc(&d, sizeof(NormCounts));
     if (e != hipSuccess) return e;
@@ -118,6 +143,7 @@ hipError_t run_norm_math_selftest(uint64_t out[5], hipStream_t s) {
     (void)hipFree(d);
     if (e != hipSuccess) return e;
     out[0] = h.inputs; out[1] = h.div_bad; out[2] = h.sqrt_bad; out[3] = h.compose_bad; out[4] = h.first_bad;
+    out[5] = h.rational_inputs; out[6] = h.rational_div_bad;
     return hipSuccess;
 }
 

@@ -67,7 +67,7 @@ hipError_t launch_spots(const ft8gpu_candidate *cands, const int32_t *counts,
 hipError_t launch_synth(const ft8gpu_synth_signal *sig_dev, int nframes, int nsig, float noise_sigma,
                         uint64_t seed, uint64_t first_frame, float *iq, hipStream_t s);
 hipError_t run_bp_math_selftest(uint64_t out[7], hipStream_t s);   // bp_selftest.hip: exhaustive check of bp_math.h
-hipError_t run_norm_math_selftest(uint64_t out[5], hipStream_t s); // bp_selftest.hip: sqrtf(24.0f / v) against exact arithmetic, every float
+hipError_t run_norm_math_selftest(uint64_t out[7], hipStream_t s); // bp_selftest.hip: sqrtf(24.0f / v) against exact arithmetic, every float
 hipError_t decode_tables_init(hipStream_t s);   // uploads the LDPC edge tables used by the BP kernel
 hipError_t launch_rx(const uint8_t *raw, int ncaptures, size_t npairs, void *scratch_sums, void *scratch_base,
                      float *iq, int normalise, hipStream_t s);

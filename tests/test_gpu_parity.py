@@ -609,6 +609,9 @@ def test_llr_scale_factor_is_correctly_rounded_on_every_float():
         r = d.selftest_norm_math()
     assert r["inputs"] == 120 * (1 << 23) + 1, r                 # every float of 120 binades and 2^60 itself
     assert r["div_bad"] == 0 and r["sqrt_bad"] == 0 and r["compose_bad"] == 0 and r["first_bad"] == 0, r
+    # ... and the divisions inside fast_tanh / fast_atanh, which the chains of ft8gpu_selftest_bp_math are compared with, are
+    # themselves the correctly rounded quotients on every input of their domains
+    assert r["rational_inputs"] > 1_100_000_000 and r["rational_div_bad"] == 0, r
 
 
 def test_decode_pipeline_form_of_the_kernel(oracle):
