@@ -491,3 +491,68 @@ def test_golden_mixed_traffic_frames(oracle):
 def ft8_pack(text):
     import rtlsdr_ft8d_amd as ft8
     return ft8.pack77(text).tobytes()
+
+
+def test_the_one_ulp_square_root_cases_are_explained_on_the_cpu(oracle):
+    """tests/golden/sqrt_ulp_cases.*: four candidates whose GPU status record differed from the oracle in rounds 1-4.  The fixture
+    holds, per max_iterations 1 ... 20, what round 4's library said and what the oracle says.  Here, without a GPU: (a) the oracle
+    still says what the fixture says; (b) the independent numpy restatement agrees with the oracle; (c) the SAME restatement with the
+    LLR scale factor sqrtf(24 / variance) taken ONE ULP LOWER reproduces every output of the old library -- which is how the
+    deviation was traced to HIP's __fsqrt_rn (the native, 1-ulp v_sqrt_f32) without looking inside the kernel."""
+    import ft8_spec_decode as spec
+    d = np.load(os.path.join(ROOT, "tests", "golden", "sqrt_ulp_cases.npz"))
+    cases = load("sqrt_ulp_cases.json")["cases"]
+    bp = spec.BP()
+    F32 = np.float32
+
+    def outputs(cw):
+        """[(ldpc_errors, a91 hex)] for max_iterations 1 .. 20 from one pass (none of these candidates converges or decides all-zero)"""
+        cw = cw.astype(F32)
+        tov = np.zeros((174, 3), F32)
+        toc = np.zeros((83, 7), F32)
+        out, best = [], 83
+        for it in range(20):
+            total = ((cw + tov[:, 0]) + tov[:, 1]) + tov[:, 2]
+            plain = (total > 0).astype(np.uint8)
+            errors = bp.check(plain)
+            assert plain.any() and errors > 0
+            best = min(best, errors)
+            out.append((best, spec.pack_bits(plain).hex()))
+            for e in range(3):
+                others = [o for o in range(3) if o != e]
+                tnm = (cw + tov[:, others[0]]) + tov[:, others[1]]
+                toc[bp.edge_row[:, e], bp.edge_pos[:, e]] = spec.fast_tanh(-tnm / F32(2))
+            new = np.zeros((174, 3), F32)
+            for e in range(3):
+                rows, pos = bp.edge_row[:, e], bp.edge_pos[:, e]
+                acc = np.ones(174, F32)
+                for j in range(7):
+                    use = (j < bp.num_rows[rows]) & (j != pos)
+                    acc = np.where(use, acc * toc[rows, j], acc).astype(F32)
+                new[:, e] = F32(-2) * spec.fast_atanh(acc)
+            tov = new
+        return out
+
+    differing = 0
+    for k, case in enumerate(cases):
+        mag = d["mag"][k]
+        c = np.zeros(1, oracle.CAND_DTYPE)
+        c[0] = tuple(int(x) for x in d["cand"][k])
+        old = [(r[0], r[1]) for r in case["by_max_iterations"]]
+        ref = [(r[2], r[3]) for r in case["by_max_iterations"]]
+        for it in (1, 8, 14, 20):                                   # (a) the oracle, spot-checked over the iteration caps
+            s = oracle.decode(mag, c, it)
+            assert (s["ldpc_errors"], s["a91"].hex()) == ref[it - 1], (k, it)
+        raw = oracle.llr(mag, c, normalise=False)
+        s1 = s2 = F32(0)
+        for v in raw:
+            s1 = F32(s1 + v)
+            s2 = F32(s2 + F32(v * v))
+        inv_n = F32(1.0) / F32(174)
+        variance = F32(F32(s2 - F32(F32(s1 * s1) * inv_n)) * inv_n)
+        norm = np.sqrt(F32(24.0) / variance, dtype=F32)
+        assert ((raw * norm).astype(F32)).tobytes() == oracle.llr(mag, c).tobytes()
+        assert outputs(raw * norm) == ref, k                        # (b)
+        assert outputs(raw * np.nextafter(norm, F32(0))) == old, k  # (c)
+        differing += sum(a != b for a, b in zip(old, ref))
+    assert differing >= len(cases)                                  # the fixture holds real differences
