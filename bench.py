@@ -496,6 +496,15 @@ def main():
             "kernel_ms_per_launch": round(dom_ms / launches, 4), "algorithmic_bytes_per_launch": BYTES_PER_FRAME * B // launches,
             "stage_ms": {k: round(v, 4) for k, v in stage_avg.items()}, "stage_ms_runs": timed_runs,
             "pipeline_achieved_GBps": round(BYTES_PER_FRAME * B / (stage_avg["total_ms"] * 1e-3) / 1e9, 2),
+            # every kernel against the HBM roof on ITS OWN algorithmic bytes (what it must read and write once):
+            # waterfall 384 000 B of IQ in + 94 208 B out; sync the 94 208 B waterfall in + the survivor lists out (about 1.5 KB);
+            # decode the waterfall cells its candidates gather (58 symbols x 8 tones x 114 candidates, at most the 94 208 B) + 48 B
+            # records; spots the records in + 1 404 B out.  Only the waterfall kernel is anywhere near a bandwidth bound.
+            "per_kernel": {k: {"own_bytes_per_frame": b, "ms": round(stage_avg[k + "_ms"], 4),
+                               "GBps": round(b * B / (stage_avg[k + "_ms"] * 1e-3) / 1e9, 1),
+                               "frac_of_hbm_peak": round(b * B / (stage_avg[k + "_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+                           for k, b in (("waterfall", 384000 + 94208), ("sync", 94208 + 1536), ("decode", 94208 + 114 * 48), ("spots", 114 * 48 + 1404))
+                           if stage_avg.get(k + "_ms", 0) > 0},
         }
         if world == 1 and not args.no_cpu_baseline and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(iq, spots, nres, min(args.cpu_frames, B), maxc)
