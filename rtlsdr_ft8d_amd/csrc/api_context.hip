@@ -63,7 +63,7 @@ int build_tables(Ft8Tables *t) {
         // local monotonicity: a window of neighbouring floats must sit on the right side
         for (uint32_t d = 1; d <= 64; d++) {
             if (ref_quant(u2f(hi + d)) < k || ref_quant(u2f(hi - d)) >= k)
-                return fail("host log10f is not monotone around quantiser threshold %d", k);
+                return ft8_fail("host log10f is not monotone around quantiser threshold %d", k);
         }
     }
     for (int k = 256; k < 260; k++) t->qthr[k] = NAN;       // `y >= qthr[256]` must be false for every y, +inf included
@@ -75,7 +75,7 @@ int build_tables(Ft8Tables *t) {
         const float y = 1E-12f + powf(10.0f, expo);
         int q = 0;
         for (int k = 1; k <= 255; k++) q += (y >= t->qthr[k]);
-        if (q != ref_quant(y)) return fail("quantiser threshold table disagrees with log10f at y=%g", (double)y);
+        if (q != ref_quant(y)) return ft8_fail("quantiser threshold table disagrees with log10f at y=%g", (double)y);
     }
     return 0;
 }
@@ -92,9 +92,9 @@ int alloc_candidate_buffers(ft8gpu_ctx *c, int cap) {
 
 int check_params(const ft8gpu_params *p) {
     if (p->max_candidates < 1 || p->max_candidates > FT8GPU_ABS_MAX_CANDIDATES)
-        return fail("max_candidates %d out of range [1, %d]", p->max_candidates, FT8GPU_ABS_MAX_CANDIDATES);
-    if (p->ldpc_iters < 1 || p->ldpc_iters > 1000) return fail("ldpc_iters %d out of range", p->ldpc_iters);
-    if (p->min_score < -32768 || p->min_score > 32767) return fail("min_score %d out of range", p->min_score);
+        return ft8_fail("max_candidates %d out of range [1, %d]", p->max_candidates, FT8GPU_ABS_MAX_CANDIDATES);
+    if (p->ldpc_iters < 1 || p->ldpc_iters > 1000) return ft8_fail("ldpc_iters %d out of range", p->ldpc_iters);
+    if (p->min_score < -32768 || p->min_score > 32767) return ft8_fail("min_score %d out of range", p->min_score);
     return 0;
 }
 
@@ -210,12 +210,12 @@ static int create_body(ft8gpu_ctx *c) {
     // keeps its three streams on three hardware queues of their own)
     for (auto &e : c->copied) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     Ft8Tables *h = (Ft8Tables *)malloc(sizeof(Ft8Tables));
-    if (!h) return fail("out of host memory");
+    if (!h) return ft8_fail("out of host memory");
     if (build_tables(h)) { free(h); return -1; }
     hipError_t e = hipMalloc(&c->d_tab, sizeof(Ft8Tables));
     if (e == hipSuccess) e = hipMemcpy(c->d_tab, h, sizeof(Ft8Tables), hipMemcpyHostToDevice);
     free(h);
-    if (e != hipSuccess) return fail("uploading the constant tables failed: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return ft8_fail("uploading the constant tables failed: %s", hipGetErrorString(e));
     HIP_TRY(decode_tables_init(c->stream));
 
     const size_t F = (size_t)c->max_frames;
@@ -232,18 +232,18 @@ static int create_body(ft8gpu_ctx *c) {
 }
 
 int ft8gpu_create(ft8gpu_ctx **out, int device, int max_frames, const ft8gpu_params *params) {
-    if (!out) return fail("ft8gpu_create: out is NULL");
+    if (!out) return ft8_fail("ft8gpu_create: out is NULL");
     *out = nullptr;
-    if (max_frames < 1) return fail("ft8gpu_create: max_frames must be >= 1");
+    if (max_frames < 1) return ft8_fail("ft8gpu_create: max_frames must be >= 1");
     if (params && check_params(params)) return -1;
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
-    if (device < 0 || device >= ndev) return fail("ft8gpu_create: device %d not present (%d visible)", device, ndev);
+    if (device < 0 || device >= ndev) return ft8_fail("ft8gpu_create: device %d not present (%d visible)", device, ndev);
     int prev = -1;
     (void)hipGetDevice(&prev);
     HIP_TRY(hipSetDevice(device));
     ft8gpu_ctx *c = new (std::nothrow) ft8gpu_ctx();
-    if (!c) { if (prev >= 0 && prev != device) (void)hipSetDevice(prev); return fail("out of host memory"); }
+    if (!c) { if (prev >= 0 && prev != device) (void)hipSetDevice(prev); return ft8_fail("out of host memory"); }
     c->device = device;
     c->max_frames = max_frames;
     if (params) c->params = *params;
@@ -302,27 +302,27 @@ int ft8gpu_set_stream(ft8gpu_ctx *c, void *hip_stream) {
 
 // pure queries: they never touch ft8gpu_last_error() (a NULL context is the one error they report)
 int ft8gpu_overlap_active(ft8gpu_ctx *c) {
-    if (!c) return fail("ctx is NULL");
+    if (!c) return ft8_fail("ctx is NULL");
     std::lock_guard<std::mutex> lock(c->mu);
     return c->overlap_ok ? 1 : 0;
 }
 
 int ft8gpu_overlap_reason(ft8gpu_ctx *c, char *buf, size_t cap) {
-    if (!c) return fail("ctx is NULL");
-    if (!buf || cap == 0) return fail("NULL buffer");
+    if (!c) return ft8_fail("ctx is NULL");
+    if (!buf || cap == 0) return ft8_fail("NULL buffer");
     std::lock_guard<std::mutex> lock(c->mu);
     snprintf(buf, cap, "%s", c->overlap_ok ? "" : c->overlap_why);
     return 0;
 }
 
 void *ft8gpu_get_stream(ft8gpu_ctx *c) {
-    if (!c) { fail("ctx is NULL"); return nullptr; }
+    if (!c) { ft8_fail("ctx is NULL"); return nullptr; }
     std::lock_guard<std::mutex> lock(c->mu);
     return (void *)c->stream;
 }
 
 int ft8gpu_set_params(ft8gpu_ctx *c, const ft8gpu_params *p) {
-    if (!c || !p) return fail("NULL argument");
+    if (!c || !p) return ft8_fail("NULL argument");
     if (check_params(p)) return -1;
     CHECK_COMMON(c, 0);
     if (p->max_candidates > c->cap_candidates) {
@@ -335,10 +335,10 @@ int ft8gpu_set_params(ft8gpu_ctx *c, const ft8gpu_params *p) {
 
 int ft8gpu_set_debug_flags(ft8gpu_ctx *c, unsigned flags) {
     CHECK_COMMON(c, 0);
-    if (flags & ~kDbgAccepted) return fail("ft8gpu_set_debug_flags: unknown bits 0x%x", flags & ~kDbgAccepted);
+    if (flags & ~kDbgAccepted) return ft8_fail("ft8gpu_set_debug_flags: unknown bits 0x%x", flags & ~kDbgAccepted);
 #ifdef FT8GPU_AB_FORMS
     if ((flags & FT8GPU_AB_HEAP_LANE_PER_FRAME) && (flags & FT8GPU_AB_HEAP_WAVE_PER_FRAME))
-        return fail("ft8gpu_set_debug_flags: FT8GPU_AB_HEAP_LANE_PER_FRAME and FT8GPU_AB_HEAP_WAVE_PER_FRAME exclude each other");
+        return ft8_fail("ft8gpu_set_debug_flags: FT8GPU_AB_HEAP_LANE_PER_FRAME and FT8GPU_AB_HEAP_WAVE_PER_FRAME exclude each other");
 #endif
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->debug_flags = flags;
@@ -346,14 +346,14 @@ int ft8gpu_set_debug_flags(ft8gpu_ctx *c, unsigned flags) {
 }
 
 int ft8gpu_selftest_bp_math(ft8gpu_ctx *c, uint64_t out[7]) {
-    if (!out) return fail("NULL argument");
+    if (!out) return ft8_fail("NULL argument");
     CHECK_COMMON(c, 0);
     HIP_TRY(run_bp_math_selftest(out, c->stream));
     return 0;
 }
 
 int ft8gpu_selftest_norm_math(ft8gpu_ctx *c, uint64_t out[7]) {
-    if (!out) return fail("NULL argument");
+    if (!out) return ft8_fail("NULL argument");
     CHECK_COMMON(c, 0);
     HIP_TRY(run_norm_math_selftest(out, c->stream));
     return 0;
@@ -368,9 +368,9 @@ int ft8gpu_enable_timing(ft8gpu_ctx *c, int on) {
 
 // mean over the (up to 32 most recent) pipeline runs recorded since ft8gpu_enable_timing(ctx, 1)
 int ft8gpu_get_timings(ft8gpu_ctx *c, ft8gpu_timings *out, int32_t *nruns) {
-    if (!c || !out) return fail("NULL argument");
+    if (!c || !out) return ft8_fail("NULL argument");
     CHECK_COMMON(c, 0);
-    if (!c->timing || c->runs == 0) return fail("no timed pipeline run recorded");
+    if (!c->timing || c->runs == 0) return ft8_fail("no timed pipeline run recorded");
     const int n = c->runs < ft8gpu_ctx::kTimingSlots ? (int)c->runs : ft8gpu_ctx::kTimingSlots;
     double acc[6] = { 0, 0, 0, 0, 0, 0 };
     int launches = 1;
@@ -412,10 +412,10 @@ int ft8gpu_synchronize(ft8gpu_ctx *c) {
 
 // device memory helpers: they act on the context's GPU (not on whatever device happens to be current)
 void *ft8gpu_dev_alloc(ft8gpu_ctx *c, size_t bytes) {
-    if (!c) { fail("ctx is NULL"); return nullptr; }
+    if (!c) { ft8_fail("ctx is NULL"); return nullptr; }
     Entry entry_(c);
     void *p = nullptr;
-    if (entry_.err != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) { fail("hipMalloc(%zu) on device %d failed", bytes, c->device); return nullptr; }
+    if (entry_.err != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) { ft8_fail("hipMalloc(%zu) on device %d failed", bytes, c->device); return nullptr; }
     return p;
 }
 void ft8gpu_dev_free(ft8gpu_ctx *c, void *p) {
@@ -429,7 +429,7 @@ void ft8gpu_dev_free(ft8gpu_ctx *c, void *p) {
 // entries needs no HIP header.
 void *ft8gpu_host_alloc(size_t bytes) {
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { fail("hipHostMalloc(%zu) failed", bytes); return nullptr; }
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { ft8_fail("hipHostMalloc(%zu) failed", bytes); return nullptr; }
     return p;
 }
 void ft8gpu_host_free(void *p) { if (p) (void)hipHostFree(p); }

@@ -20,8 +20,8 @@ int ft8gpu_rx_decimate(ft8gpu_ctx *c, const uint8_t *raw, int ncaptures, size_t 
                        int normalise, int flags) {
     CHECK_COMMON(c, ncaptures);
     if (ncaptures == 0) return 0;
-    if (!raw || !iq) return fail("NULL array argument");
-    if (npairs % 8 != 0) return fail("npairs must be a multiple of 8 (whole 16-byte units; the reference's buffers are multiples of 8 bytes)");
+    if (!raw || !iq) return ft8_fail("NULL array argument");
+    if (npairs % 8 != 0) return ft8_fail("npairs must be a multiple of 8 (whole 16-byte units; the reference's buffers are multiples of 8 bytes)");
     const size_t nblocks = npairs / 751 > (size_t)kNSamples ? (size_t)kNSamples : npairs / 751;
     const size_t raw_bytes = (size_t)ncaptures * npairs * 2, iq_bytes = (size_t)ncaptures * 2 * kNSamples * sizeof(float);
     const size_t sums_bytes = (size_t)ncaptures * (nblocks + 1) * 16;
@@ -32,7 +32,7 @@ int ft8gpu_rx_decimate(ft8gpu_ctx *c, const uint8_t *raw, int ncaptures, size_t 
     if (grow_buffer(&c->d_rx_sums, &c->rx_sums_cap, sums_bytes)) return -1;
     if (grow_buffer(&c->d_rx_p2, &c->rx_p2_cap, p2_bytes)) return -1;
     if (flags & FT8GPU_DEVICE_PTRS) {
-        if (((uintptr_t)raw & 15) != 0) return fail("raw must be 16-byte aligned");
+        if (((uintptr_t)raw & 15) != 0) return ft8_fail("raw must be 16-byte aligned");
         HIP_TRY(launch_rx(raw, ncaptures, npairs, c->d_rx_sums, c->d_rx_p2, iq, normalise, c->stream));
     } else {
         if (grow_buffer((void **)&c->d_rx_raw, &c->rx_raw_cap, raw_bytes)) return -1;
@@ -67,7 +67,7 @@ static int build_report_prefix(const ft8gpu_report_info *info, ReportPrefix *out
     };
     auto text = [&](const char *s, size_t cap) -> int {      // one length byte + characters
         const size_t len = strnlen(s, cap);
-        if (len == cap) return fail("ft8gpu_report_info string is not NUL-terminated");
+        if (len == cap) return ft8_fail("ft8gpu_report_info string is not NUL-terminated");
         b[n++] = (unsigned char)len;
         memcpy(b + n, s, len);
         n += len;
@@ -101,11 +101,11 @@ int ft8gpu_pskreporter_datagrams(ft8gpu_ctx *c, const struct decoder_results *de
                                  uint8_t *datagrams, int32_t *lengths, int flags) {
     CHECK_COMMON(c, nframes);
     if (nframes == 0) return 0;
-    if (!decodes || !n_results || !info || !datagrams || !lengths) return fail("NULL array argument");
+    if (!decodes || !n_results || !info || !datagrams || !lengths) return ft8_fail("NULL array argument");
     ReportPrefix pre;
     if (build_report_prefix(info, &pre)) return -1;
     if (flags & FT8GPU_DEVICE_PTRS) {
-        if (((uintptr_t)datagrams & 15) != 0) return fail("datagrams must be 16-byte aligned");
+        if (((uintptr_t)datagrams & 15) != 0) return ft8_fail("datagrams must be 16-byte aligned");
         HIP_TRY(launch_report(decodes, n_results, nframes, pre, unixtimes, datagrams, lengths, c->stream));
         return 0;
     }
@@ -136,8 +136,8 @@ int ft8gpu_synth_frames_at(ft8gpu_ctx *c, const ft8gpu_synth_signal *signals, in
                            float noise_sigma, uint64_t seed, uint64_t first_frame, float *iq_dev) {
     CHECK_COMMON(c, nframes);
     if (nframes == 0) return 0;
-    if (nsig < 0 || nsig > 64) return fail("nsig_per_frame %d out of range [0, 64]", nsig);
-    if (!iq_dev || (nsig > 0 && !signals)) return fail("NULL array argument");
+    if (nsig < 0 || nsig > 64) return ft8_fail("nsig_per_frame %d out of range [0, 64]", nsig);
+    if (!iq_dev || (nsig > 0 && !signals)) return ft8_fail("NULL array argument");
     const size_t bytes = (size_t)nframes * (nsig > 0 ? nsig : 1) * sizeof(ft8gpu_synth_signal);
     if (bytes > c->sigs_cap) {
         if (c->d_sigs) (void)hipFree(c->d_sigs);

@@ -31,7 +31,7 @@ static int run_shards(ft8gpu_ctx *const *ctxs, int ndev, const float *const *iq_
     if (count[0] > 0) work(0);
     latch.wait();
     for (int g = 0; g < ndev; ++g)
-        if (rc[g]) return fail("shard %d of %d (frames [%d, %d)): %s", g, ndev, first[g], first[g] + count[g], why[g].c_str());
+        if (rc[g]) return ft8_fail("shard %d of %d (frames [%d, %d)): %s", g, ndev, first[g], first[g] + count[g], why[g].c_str());
     return 0;
 }
 
@@ -39,15 +39,15 @@ extern "C" {
 
 int ft8gpu_decode_batch_multi(ft8gpu_ctx *const *ctxs, int ndev, const float *iq, int nframes,
                               struct decoder_results *decodes, int32_t *n_results) {
-    if (!ctxs || ndev < 1) return fail("ft8gpu_decode_batch_multi: no contexts");
-    if (nframes < 0) return fail("nframes < 0");
+    if (!ctxs || ndev < 1) return ft8_fail("ft8gpu_decode_batch_multi: no contexts");
+    if (nframes < 0) return ft8_fail("nframes < 0");
     if (nframes == 0) return 0;
-    if (!iq || !decodes || !n_results) return fail("NULL array argument");
+    if (!iq || !decodes || !n_results) return ft8_fail("NULL array argument");
     std::vector<const float *> iq_of((size_t)ndev);
     std::vector<int> first((size_t)ndev), count((size_t)ndev);
     for (int g = 0; g < ndev; ++g) {
-        if (!ctxs[g]) return fail("ctxs[%d] is NULL", g);
-        for (int h = 0; h < g; ++h) if (ctxs[h] == ctxs[g]) return fail("ctxs[%d] and ctxs[%d] are the same context", h, g);
+        if (!ctxs[g]) return ft8_fail("ctxs[%d] is NULL", g);
+        for (int h = 0; h < g; ++h) if (ctxs[h] == ctxs[g]) return ft8_fail("ctxs[%d] and ctxs[%d] are the same context", h, g);
         first[g] = (int)((long long)nframes * g / ndev);
         count[g] = (int)((long long)nframes * (g + 1) / ndev) - first[g];
         iq_of[g] = iq + (size_t)first[g] * 2 * kNSamples;
@@ -57,19 +57,19 @@ int ft8gpu_decode_batch_multi(ft8gpu_ctx *const *ctxs, int ndev, const float *iq
 
 int ft8gpu_decode_batch_multi_dev(ft8gpu_ctx *const *ctxs, int ndev, const float *const *iq_dev, const int *nframes_dev,
                                   struct decoder_results *decodes, int32_t *n_results) {
-    if (!ctxs || ndev < 1) return fail("ft8gpu_decode_batch_multi_dev: no contexts");
-    if (!iq_dev || !nframes_dev || !decodes || !n_results) return fail("NULL array argument");
+    if (!ctxs || ndev < 1) return ft8_fail("ft8gpu_decode_batch_multi_dev: no contexts");
+    if (!iq_dev || !nframes_dev || !decodes || !n_results) return ft8_fail("NULL array argument");
     std::vector<int> first((size_t)ndev), count((size_t)ndev);
     long long total = 0;
     for (int g = 0; g < ndev; ++g) {
-        if (!ctxs[g]) return fail("ctxs[%d] is NULL", g);
-        for (int h = 0; h < g; ++h) if (ctxs[h] == ctxs[g]) return fail("ctxs[%d] and ctxs[%d] are the same context", h, g);
-        if (nframes_dev[g] < 0) return fail("nframes_dev[%d] < 0", g);
-        if (nframes_dev[g] > 0 && !iq_dev[g]) return fail("iq_dev[%d] is NULL", g);
+        if (!ctxs[g]) return ft8_fail("ctxs[%d] is NULL", g);
+        for (int h = 0; h < g; ++h) if (ctxs[h] == ctxs[g]) return ft8_fail("ctxs[%d] and ctxs[%d] are the same context", h, g);
+        if (nframes_dev[g] < 0) return ft8_fail("nframes_dev[%d] < 0", g);
+        if (nframes_dev[g] > 0 && !iq_dev[g]) return ft8_fail("iq_dev[%d] is NULL", g);
         first[g] = (int)total;
         count[g] = nframes_dev[g];
         total += nframes_dev[g];
-        if (total > 0x7FFFFFFF) return fail("too many frames");
+        if (total > 0x7FFFFFFF) return ft8_fail("too many frames");
     }
     return run_shards(ctxs, ndev, iq_dev, first.data(), count.data(), true, decodes, n_results);
 }
@@ -135,31 +135,31 @@ std::vector<GatherGroup *> g_groups;
 extern "C" int ft8gpu_gather_spots(ft8gpu_ctx *const *ctxs, int ndev, const struct decoder_results *const *decodes_dev,
                                    const int32_t *const *n_results_dev, int frames_per_dev,
                                    struct decoder_results *const *all_decodes_dev, int32_t *const *all_n_results_dev) {
-    if (!ctxs || ndev < 1) return fail("ft8gpu_gather_spots: no contexts");
-    if (!decodes_dev || !n_results_dev || !all_decodes_dev || !all_n_results_dev) return fail("NULL array argument");
-    if (frames_per_dev < 0) return fail("frames_per_dev < 0");
+    if (!ctxs || ndev < 1) return ft8_fail("ft8gpu_gather_spots: no contexts");
+    if (!decodes_dev || !n_results_dev || !all_decodes_dev || !all_n_results_dev) return ft8_fail("NULL array argument");
+    if (frames_per_dev < 0) return ft8_fail("frames_per_dev < 0");
     if (frames_per_dev == 0) return 0;
     std::vector<int> devs((size_t)ndev);
     for (int g = 0; g < ndev; ++g) {
-        if (!ctxs[g]) return fail("ctxs[%d] is NULL", g);
-        if (!decodes_dev[g] || !n_results_dev[g] || !all_decodes_dev[g] || !all_n_results_dev[g]) return fail("NULL buffer for shard %d", g);
+        if (!ctxs[g]) return ft8_fail("ctxs[%d] is NULL", g);
+        if (!decodes_dev[g] || !n_results_dev[g] || !all_decodes_dev[g] || !all_n_results_dev[g]) return ft8_fail("NULL buffer for shard %d", g);
         devs[g] = ctxs[g]->device;
         for (int h = 0; h < g; ++h)
-            if (devs[h] == devs[g]) return fail("ft8gpu_gather_spots: ctxs[%d] and ctxs[%d] are on the same GPU %d (RCCL needs one rank per device; "
+            if (devs[h] == devs[g]) return ft8_fail("ft8gpu_gather_spots: ctxs[%d] and ctxs[%d] are on the same GPU %d (RCCL needs one rank per device; "
                                                 "several contexts on one GPU gather on the host: ft8gpu_decode_batch_multi_dev)", h, g, devs[g]);
     }
     Rccl *r = rccl();
-    if (!r->lib) return fail("RCCL unavailable: %s", r->why.c_str());
+    if (!r->lib) return ft8_fail("RCCL unavailable: %s", r->why.c_str());
     std::lock_guard<std::mutex> lock(g_gather_mu);
     GatherGroup *grp = nullptr;
     for (GatherGroup *c : g_groups) if (c->devices == devs) grp = c;
     if (!grp) {
         grp = new (std::nothrow) GatherGroup();
-        if (!grp) return fail("out of host memory");
+        if (!grp) return ft8_fail("out of host memory");
         grp->devices = devs;
         grp->comms.assign((size_t)ndev, nullptr);
         const int rc = r->CommInitAll(grp->comms.data(), ndev, devs.data());
-        if (rc != 0) { const char *e = r->GetErrorString(rc); delete grp; return fail("ncclCommInitAll failed: %s", e ? e : "?"); }
+        if (rc != 0) { const char *e = r->GetErrorString(rc); delete grp; return ft8_fail("ncclCommInitAll failed: %s", e ? e : "?"); }
         g_groups.push_back(grp);
     }
     int prev = -1;
@@ -176,7 +176,7 @@ extern "C" int ft8gpu_gather_spots(ft8gpu_ctx *const *ctxs, int ndev, const stru
     const int rc_end = r->GroupEnd();
     if (prev >= 0) (void)hipSetDevice(prev);
     if (rc == 0) rc = rc_end;
-    if (rc != 0) { const char *e = r->GetErrorString(rc); return fail("RCCL all-gather failed: %s", e ? e : "?"); }
+    if (rc != 0) { const char *e = r->GetErrorString(rc); return ft8_fail("RCCL all-gather failed: %s", e ? e : "?"); }
     return 0;       // enqueued on every context's stream; ft8gpu_synchronize(ctxs[g]) or a later entry of that context waits for it
 }
 

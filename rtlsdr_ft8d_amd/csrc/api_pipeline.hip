@@ -130,7 +130,7 @@ extern "C" int ft8gpu_decode_batch(ft8gpu_ctx *c, const float *iq, int nframes, 
                         int32_t *n_results, int flags) {
     CHECK_COMMON(c, nframes);
     if (nframes == 0) return 0;
-    if (!iq || !decodes || !n_results) return fail("NULL array argument");
+    if (!iq || !decodes || !n_results) return ft8_fail("NULL array argument");
     const size_t frame_floats = 2 * (size_t)kNSamples;
     for (int f0 = 0; f0 < nframes; f0 += c->max_frames) {
         const int n = (nframes - f0 < c->max_frames) ? nframes - f0 : c->max_frames;
@@ -171,7 +171,7 @@ extern "C" int ft8gpu_decode_batch(ft8gpu_ctx *c, const float *iq, int nframes, 
 int decode_dev_to_host(ft8gpu_ctx *c, const float *d_iq, int nframes, struct decoder_results *decodes, int32_t *n_results) {
     CHECK_COMMON(c, nframes);
     if (nframes == 0) return 0;
-    if (!d_iq || !decodes || !n_results) return fail("NULL array argument");
+    if (!d_iq || !decodes || !n_results) return ft8_fail("NULL array argument");
     const size_t frame_floats = 2 * (size_t)kNSamples;
     for (int f0 = 0; f0 < nframes; f0 += c->max_frames) {
         const int n = (nframes - f0 < c->max_frames) ? nframes - f0 : c->max_frames;

@@ -7,7 +7,7 @@ extern "C" {
 int ft8gpu_waterfall(ft8gpu_ctx *c, const float *iq, int nframes, uint8_t *mag, int flags) {
     CHECK_COMMON(c, nframes);
     if (nframes == 0) return 0;
-    if (!iq || !mag) return fail("NULL array argument");
+    if (!iq || !mag) return ft8_fail("NULL array argument");
     const size_t frame_floats = 2 * (size_t)kNSamples;
     for (int f0 = 0; f0 < nframes; f0 += c->max_frames) {
         const int n = (nframes - f0 < c->max_frames) ? nframes - f0 : c->max_frames;
@@ -27,7 +27,7 @@ int ft8gpu_waterfall(ft8gpu_ctx *c, const float *iq, int nframes, uint8_t *mag, 
 int ft8gpu_find_sync(ft8gpu_ctx *c, const uint8_t *mag, int nframes, ft8gpu_candidate *cands, int32_t *counts, int flags) {
     CHECK_COMMON(c, nframes);
     if (nframes == 0) return 0;
-    if (!mag || !cands || !counts) return fail("NULL array argument");
+    if (!mag || !cands || !counts) return ft8_fail("NULL array argument");
     const int mc = c->params.max_candidates;
     for (int f0 = 0; f0 < nframes; f0 += c->max_frames) {
         const int n = (nframes - f0 < c->max_frames) ? nframes - f0 : c->max_frames;
@@ -50,7 +50,7 @@ int ft8gpu_find_sync(ft8gpu_ctx *c, const uint8_t *mag, int nframes, ft8gpu_cand
 int ft8gpu_score_map(ft8gpu_ctx *c, const uint8_t *mag, int nframes, int16_t *scores, int flags) {
     CHECK_COMMON(c, nframes);
     if (nframes == 0) return 0;
-    if (!mag || !scores) return fail("NULL array argument");
+    if (!mag || !scores) return ft8_fail("NULL array argument");
     for (int f0 = 0; f0 < nframes; f0 += c->max_frames) {
         const int n = (nframes - f0 < c->max_frames) ? nframes - f0 : c->max_frames;
         const bool dev = flags & FT8GPU_DEVICE_PTRS;
@@ -71,7 +71,7 @@ int ft8gpu_decode_candidates(ft8gpu_ctx *c, const uint8_t *mag, const ft8gpu_can
                              int nframes, ft8gpu_decode_status *status, int flags) {
     CHECK_COMMON(c, nframes);
     if (nframes == 0) return 0;
-    if (!mag || !cands || !counts || !status) return fail("NULL array argument");
+    if (!mag || !cands || !counts || !status) return ft8_fail("NULL array argument");
     const int mc = c->params.max_candidates;
     // the stage entry reports the exact ldpc_errors; FT8GPU_DBG_PIPELINE_FORM runs the form of the
     // kernel the batch pipeline uses instead (test hook: every field but ldpc_errors must agree)
@@ -103,7 +103,7 @@ int ft8gpu_collect_spots(ft8gpu_ctx *c, const ft8gpu_candidate *cands, const int
                          int32_t *n_results, int flags) {
     CHECK_COMMON(c, nframes);
     if (nframes == 0) return 0;
-    if (!cands || !counts || !status || !decodes || !n_results) return fail("NULL array argument");
+    if (!cands || !counts || !status || !decodes || !n_results) return ft8_fail("NULL array argument");
     const int mc = c->params.max_candidates;
     for (int f0 = 0; f0 < nframes; f0 += c->max_frames) {
         const int n = (nframes - f0 < c->max_frames) ? nframes - f0 : c->max_frames;

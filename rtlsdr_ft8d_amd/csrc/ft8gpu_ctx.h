@@ -6,16 +6,15 @@
 #include <mutex>
 #include <stddef.h>
 
-// ft8gpu_last_error(): thread-local text, written by fail() only (api_context.hip)
+// ft8gpu_last_error(): thread-local text, written by ft8_fail() only (api_context.hip)
 int ft8_fail(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 char *ft8_err_buffer();                       // the calling thread's buffer (kErrBytes), for hand-overs between threads
 constexpr size_t kErrBytes = 512;
-#define fail ft8_fail
 
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
         hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+        if (e_ != hipSuccess) return ft8_fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
 struct ft8gpu_ctx {
@@ -83,8 +82,8 @@ struct Entry {
 };
 
 #define CHECK_COMMON(c, n)                                                              \
-    if (!(c)) return fail("ctx is NULL");                                               \
-    if ((n) < 0) return fail("nframes < 0");                                            \
+    if (!(c)) return ft8_fail("ctx is NULL");                                               \
+    if ((n) < 0) return ft8_fail("nframes < 0");                                            \
     Entry entry_(c);                                                                    \
     HIP_TRY(entry_.err);
 
