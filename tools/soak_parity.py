@@ -21,6 +21,9 @@ def main():
                     help="signals all over the edges of the search window: tone 0 between -20 and 1620 Hz (bins 0 and 255, aliasing above "
                          "1600 Hz) and start times between -1.5 and +3.0 s (frames that begin before the window or run out of it): real decodes "
                          "where the sync score drops terms and the LLR extraction reads blocks that do not exist")
+    ap.add_argument("--vary-min-score", action="store_true",
+                    help="draw K_MIN_SCORE per batch from 10, 10, 5, 0, -3, 20, 30 (the reference fixes 10, rtlsdr_ft8d.h:43; the run-time form must "
+                         "follow the same rules at any threshold: at 0 and below every position of the scan survives the gate)")
     ap.add_argument("--records", "--stages", action="store_true", dest="records",
                     help="also compare every stage boundary of every frame through the stage entries: all 94 208 waterfall bytes, the ordered "
                          "candidate list, and the 48-byte status record of EVERY candidate (parity errors, iterations, packed bits, CRCs, unpack "
@@ -56,7 +59,8 @@ def main():
         nsig = int(rng.integers(0, 61))
         lo_snr = float(rng.uniform(-26, -10)); hi_snr = lo_snr + float(rng.uniform(2, 20))
         cap = int(rng.choice([120, 120, 120, 60, 240, 480]))
-        dec.set_params(max_candidates=cap)
+        min_score = int(rng.choice([10, 10, 5, 0, -3, 20, 30])) if args.vary_min_score else 10
+        dec.set_params(min_score=min_score, max_candidates=cap)
         sig, _ = workload.frame_signals(1_000_000 + (args.seed - 123) * 10_000_000 + b * B, B, nsig, tones, snr_range=(lo_snr, hi_snr),
                                         dup_fraction=workload.MIXED_DUP_FRACTION if mixed else 0.0,
                                         **(dict(f_range=(-20.0, 1620.0), dt_range=(-1.5, 3.0)) if args.edges else {}))
@@ -67,7 +71,7 @@ def main():
         dec.synchronize()
         g = spots.cpu().numpy().view(ft8.RESULT_DTYPE).reshape(B, 50)
         gn = nres.cpu().numpy()
-        rdec, rn = O.subsystem_batch(iq.cpu().numpy(), O.default_params(10, cap, 20), cores, decodes=start)
+        rdec, rn = O.subsystem_batch(iq.cpu().numpy(), O.default_params(min_score, cap, 20), cores, decodes=start)
         mism = [k for k in range(B) if gn[k] != rn[k] or g[k].tobytes() != rdec[k].tobytes()]
         if args.records:
             st_c = torch.zeros((B, cap, 48), dtype=torch.uint8, device="cuda")       # [B][cap] records and candidates for this batch's cap
@@ -83,7 +87,7 @@ def main():
             ref_mag = O.waterfall_batch(iq.cpu().numpy(), False, cores)                       # every byte of every waterfall
             wdiff = (h_mag != ref_mag)
             wf_bad_cells += int(wdiff.sum()); wf_bad_frames += int(wdiff.any(axis=1).sum())
-            ref_cands, ref_counts = O.find_sync_batch(ref_mag, cap, 10, cores)                # the ordered candidate lists
+            ref_cands, ref_counts = O.find_sync_batch(ref_mag, cap, min_score, cores)                # the ordered candidate lists
             cand_bad_frames += int(((h_counts != ref_counts) | (h_cands.view(np.uint64) != ref_cands.view(np.uint64)).any(axis=1)).sum())
             want = O.decode_candidates_batch(h_mag, h_cands, h_counts, 20, cores)
             got = st_c.cpu().numpy()
@@ -94,9 +98,9 @@ def main():
                 print(f"batch {b}: {rb} candidate records differ", flush=True)
         w = int(sum(1 for k in range(B) for j in range(min(int(gn[k]), 50)) if g[k, j].tobytes() != stale_rec)) if mixed else int(np.minimum(gn, 50).sum())
         bad += len(mism); total += B; msgs += int(gn.sum()); written += w
-        print(f"batch {b}: nsig {nsig} snr [{lo_snr:.0f},{hi_snr:.0f}] cap {cap}: {int(gn.sum())} messages, {w} CQ spots, mismatching frames {len(mism)}", flush=True)
+        print(f"batch {b}: nsig {nsig} snr [{lo_snr:.0f},{hi_snr:.0f}] cap {cap} min_score {min_score}: {int(gn.sum())} messages, {w} CQ spots, mismatching frames {len(mism)}", flush=True)
     print(json.dumps({"frames": total, "messages": msgs, "cq_spots_written": written, "mismatching_frames": bad, "seconds": round(time.time() - t0, 1), "seed": args.seed,
-                      "batches": args.batches, "traffic": args.traffic, "edges": bool(args.edges), "initial_record_byte": fill, "messages_per_frame": round(msgs / max(total, 1), 3),
+                      "batches": args.batches, "traffic": args.traffic, "edges": bool(args.edges), "vary_min_score": bool(args.vary_min_score), "initial_record_byte": fill, "messages_per_frame": round(msgs / max(total, 1), 3),
                       "cq_spots_per_frame": round(written / max(total, 1), 3), "build_id": build_id,
                       **({"waterfall_cells_compared": total * ft8.MAG_ARRAY, "waterfall_cells_differing": wf_bad_cells, "waterfall_frames_differing": wf_bad_frames,
                           "candidate_lists_differing": cand_bad_frames, "candidate_records_compared": rec_total, "candidate_records_decoded_ok": rec_ok,
