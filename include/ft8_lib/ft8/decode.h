@@ -65,7 +65,14 @@ int ft8_find_sync(const waterfall_t *power, int num_candidates, candidate_t heap
 
 /* rtlsdr_ft8d.c:1476: LLR extraction, normalisation, LDPC BP (max_iterations), CRC-14, unpack77 for one
  * candidate.  GPU: ft8_decode_kernel; the first call after ft8_find_sync() on the same waterfall decodes the
- * whole candidate list in one launch and later calls for candidates of that list are answered from it. */
+ * whole candidate list in one launch and later calls for candidates of that list are answered from it.
+ *
+ * ASSUMPTION the remembered list rests on: "the same waterfall" means the same `power->mag` POINTER whose 94 208 bytes still
+ * hash (64-bit multiply-mix, recomputed on every call, about 10 us) to what the last ft8_find_sync() saw.  Another pointer,
+ * changed bytes, a candidate that is not in the list, or no preceding ft8_find_sync() all take the one-candidate launch:
+ * the answer is always the pure function of (bytes, candidate, max_iterations) unless rewritten bytes collide with the
+ * old ones in that hash (2^-64 per call).  The reference never rewrites the buffer between the two calls
+ * (rtlsdr_ft8d.c:1450-1476 work on one stack array).  Both functions serialise on one process-wide lock. */
 bool ft8_decode(const waterfall_t *power, const candidate_t *cand, message_t *message, int max_iterations,
                 decode_status_t *status);
 

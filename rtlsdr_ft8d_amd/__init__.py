@@ -88,11 +88,11 @@ def _hash16(paths):
 
 def source_build_id():
     """what ft8gpu_build_id() of a library built from THIS tree returns (csrc/Makefile computes the same two hashes):
-    "<dev>.<all>" -- device sources (csrc/*.hip, *.h), and every source of the library (+ csrc/*.c, Makefile, include/)"""
+    "<dev>.<all>" -- device sources (csrc/*.hip, *.h), and every source of the library (+ csrc/*.c, Makefile, the linker version script, include/)"""
     d = os.path.join(_HERE, "csrc")
     inc = os.path.join(os.path.dirname(_HERE), "include")
     dev = sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")), key=os.path.basename)
-    rest = sorted(glob.glob(os.path.join(d, "*.c")), key=os.path.basename) + [os.path.join(d, "Makefile"), os.path.join(inc, "ft8gpu.h")] + \
+    rest = sorted(glob.glob(os.path.join(d, "*.c")), key=os.path.basename) + [os.path.join(d, "Makefile"), os.path.join(d, "libft8gpu.map"), os.path.join(inc, "ft8gpu.h")] + \
         sorted(glob.glob(os.path.join(inc, "ft8_lib", "ft8", "*.h")), key=os.path.basename)
     return f"{_hash16(dev)}.{_hash16(dev + rest)}"
 
@@ -509,15 +509,21 @@ class PinnedArray:
         self._buf = (C.c_char * self.nbytes).from_address(self.ptr)
         self._base = np.frombuffer(self._buf, dtype=dtype)          # every view of `array` keeps a reference to this object
         self.array = self._base.reshape(shape)
+        self._quiet = self._refs()              # the counts with no outside reference, measured (not assumed per CPython version)
+
+    def _refs(self):
+        import sys
+        return sys.getrefcount(self._base), sys.getrefcount(self.array)
 
     def close(self):
+        """frees the pinned memory; raises -- and changes NOTHING, `array` stays usable -- while outside references to
+        `array` or views of it are alive"""
         if self.ptr:
-            import sys
-            self.array = None
-            # references to the base array: self._base, getrefcount's argument -- anything beyond is a live view
-            extra = sys.getrefcount(self._base) - 2
+            now = self._refs()
+            extra = (now[0] - self._quiet[0]) + (now[1] - self._quiet[1])
             if extra > 0:
-                raise Ft8GpuError(f"PinnedArray.close(): {extra} view(s) of the pinned buffer are still alive; drop them first")
+                raise Ft8GpuError(f"PinnedArray.close(): {extra} reference(s) to the pinned buffer (`array` or views of it) are still alive; drop them first")
+            self.array = None
             self._base = None
             self._buf = None
             load_library().ft8gpu_host_free(C.c_void_p(self.ptr))
@@ -526,6 +532,10 @@ class PinnedArray:
     def __del__(self):
         try:
             self.close()
+        except Ft8GpuError as e:
+            import warnings
+            warnings.warn(f"PinnedArray collected while views of it are alive: {self.nbytes} bytes of pinned host memory are NOT freed ({e})",
+                          ResourceWarning, source=self)
         except Exception:
             pass
 

@@ -81,11 +81,22 @@ int build_tables(Ft8Tables *t) {
 }
 
 
+// All or nothing: both new buffers exist before the old pair is released, so a failed allocation (ft8gpu_set_params growing
+// the cap under memory pressure) leaves the context exactly as it was -- old buffers, old cap_candidates -- and returns -1.
 int alloc_candidate_buffers(ft8gpu_ctx *c, int cap) {
-    if (c->d_cands) { (void)hipFree(c->d_cands); c->d_cands = nullptr; }
-    if (c->d_status) { (void)hipFree(c->d_status); c->d_status = nullptr; }
-    HIP_TRY(hipMalloc(&c->d_cands, (size_t)c->max_frames * cap * sizeof(ft8gpu_candidate)));
-    HIP_TRY(hipMalloc(&c->d_status, (size_t)c->max_frames * cap * sizeof(ft8gpu_decode_status)));
+    ft8gpu_candidate *cands = nullptr;
+    ft8gpu_decode_status *status = nullptr;
+    if (hipMalloc(&cands, (size_t)c->max_frames * cap * sizeof(ft8gpu_candidate)) != hipSuccess ||
+        hipMalloc(&status, (size_t)c->max_frames * cap * sizeof(ft8gpu_decode_status)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (cands) (void)hipFree(cands);
+        return ft8_fail("out of device memory for %d candidates x %d frames (the context keeps its %d-candidate buffers)", cap, c->max_frames,
+                        c->cap_candidates);
+    }
+    if (c->d_cands) (void)hipFree(c->d_cands);          // hipFree waits for work that still uses the old pair
+    if (c->d_status) (void)hipFree(c->d_status);
+    c->d_cands = cands;
+    c->d_status = status;
     c->cap_candidates = cap;
     return 0;
 }

@@ -3,7 +3,10 @@
 #include "ft8gpu_ctx.h"
 #include "shard_pool.h"
 
+#include <algorithm>
 #include <dlfcn.h>
+#include <functional>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -166,9 +169,16 @@ extern "C" int ft8gpu_gather_spots(ft8gpu_ctx *const *ctxs, int ndev, const stru
     (void)hipGetDevice(&prev);
     const size_t rec_bytes = (size_t)frames_per_dev * kMaxMessages * sizeof(struct decoder_results);
     const size_t cnt_bytes = (size_t)frames_per_dev * sizeof(int32_t);
+    // RCCL enqueues the grouped collectives on the contexts' streams at ncclGroupEnd(), not at the ncclAllGather calls: every
+    // context stays locked from GroupStart to GroupEnd (in address order -- the one lock order any multi-context entry may use),
+    // so that a concurrent ft8gpu_set_stream / ft8gpu_destroy cannot replace or destroy a stream RCCL is launching on.
+    std::vector<ft8gpu_ctx *> order(ctxs, ctxs + ndev);
+    std::sort(order.begin(), order.end(), std::less<ft8gpu_ctx *>());
+    std::vector<std::unique_lock<std::mutex>> held;
+    held.reserve((size_t)ndev);
+    for (ft8gpu_ctx *c : order) held.emplace_back(c->mu);
     int rc = r->GroupStart();
     for (int g = 0; g < ndev && rc == 0; ++g) {
-        std::lock_guard<std::mutex> cl(ctxs[g]->mu);
         (void)hipSetDevice(devs[g]);
         rc = r->AllGather(decodes_dev[g], all_decodes_dev[g], rec_bytes, kNcclUint8, grp->comms[g], ctxs[g]->stream);
         if (rc == 0) rc = r->AllGather(n_results_dev[g], all_n_results_dev[g], cnt_bytes, kNcclUint8, grp->comms[g], ctxs[g]->stream);

@@ -112,7 +112,10 @@ __global__ __launch_bounds__(256) void norm_math_exhaustive(NormCounts *out, uin
         const float s = __builtin_sqrtf(q);
         const double r = __builtin_fabs((double)q * (double)v - 24.0);
         if (r > half_ulp(q) * (double)v) { ++db; bad = bits; }
-        const double h = half_ulp(s), lo = (double)s - h, hi = (double)s + h;
+        // rounding boundaries of s: the midpoints to its two neighbours.  Below a power of two the spacing halves, so the lower
+        // midpoint of s = 2^k is s - h/2, not s - h (q = pred(4^k): its root lies in (s - h, s - h/2) and must round to pred(s)).
+        // lo and hi have at most 26 significant bits: their squares are exact in binary64.
+        const double h = half_ulp(s), lo = (double)s - ((__float_as_uint(s) & 0x7FFFFFu) == 0 ? 0.5 * h : h), hi = (double)s + h;
         if (!(lo * lo < (double)q && (double)q < hi * hi)) { ++sb; bad = bits; }
         if (__float_as_uint(bpm::llr_norm_factor(v)) != __float_as_uint(s)) { ++cb; bad = bits; }
     }

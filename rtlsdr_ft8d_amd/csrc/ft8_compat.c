@@ -94,17 +94,34 @@ void ft8_subsystem(float *iSamples, float *qSamples, uint32_t samples_len,
  * in one launch and the following calls are answered from that result.  ft8_decode() is a pure function of
  * (waterfall, candidate, max_iterations): a candidate that is not in the remembered list, another waterfall or
  * changed waterfall bytes simply take the one-candidate path.
+ *
+ * THE ASSUMPTION (also in include/ft8_lib/ft8/decode.h and INTEGRATION.md 1b): ft8_decode() answers from the list the last
+ * ft8_find_sync() remembered when it is handed the same `mag` POINTER and the 64-bit hash of the bytes behind it is the one
+ * ft8_find_sync() took.  The hash is recomputed on every call; a caller that rewrites the buffer between the two calls is
+ * served a fresh decode unless the new bytes collide with the old ones in a 64-bit multiply-mix hash (chance 2^-64 per
+ * call; the reference never rewrites: one stack buffer from :1450 to :1476).
  * ------------------------------------------------------------------------------------------- */
 
+/* 64-bit multiply-mix hash of the 94 208 waterfall bytes (about 10 us).  Four chained lanes, each step
+ * h = (rotl(h) ^ word) * odd constant: a bijection of the lane state for a given word AND of the word for a given state, so a
+ * change confined to one 64-bit word always changes the hash, and the chaining makes it position dependent -- moving or
+ * swapping bytes (which an additive sum, or sum of sums, can miss) collides only by chance, 2^-64.  Not cryptographic: it
+ * guards against a caller that reuses a buffer, not against an adversary. */
+static inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static inline uint64_t fmix64(uint64_t x) { x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull; x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull; x ^= x >> 33; return x; }
+
 static uint64_t waterfall_checksum(const uint8_t *mag) {
-    const uint64_t *w = (const uint64_t *)(const void *)mag;      /* MAG_ARRAY is a multiple of 8; rows are byte arrays */
-    uint64_t a = 0x9E3779B97F4A7C15ull, b = 0;
-    if (((uintptr_t)mag & 7) != 0) {
-        for (int i = 0; i < FT8GPU_MAG_ARRAY; i++) { a = (a ^ mag[i]) * 0x100000001B3ull; }
-        return a;
+    _Static_assert(FT8GPU_MAG_ARRAY % 32 == 0, "four 64-bit lanes per step");
+    uint64_t h0 = 0x9E3779B97F4A7C15ull, h1 = 0xC2B2AE3D27D4EB4Full, h2 = 0x165667B19E3779F9ull, h3 = 0x27D4EB2F165667C5ull;
+    for (int i = 0; i < FT8GPU_MAG_ARRAY; i += 32) {
+        uint64_t w[4];
+        memcpy(w, mag + i, sizeof w);                       /* any alignment */
+        h0 = (rotl64(h0, 29) ^ w[0]) * 0x9FB21C651E98DF25ull;
+        h1 = (rotl64(h1, 31) ^ w[1]) * 0xD6E8FEB86659FD93ull;
+        h2 = (rotl64(h2, 27) ^ w[2]) * 0xA0761D6478BD642Full;
+        h3 = (rotl64(h3, 33) ^ w[3]) * 0xE7037ED1A0B428DBull;
     }
-    for (int i = 0; i < FT8GPU_MAG_ARRAY / 8; i++) { a += w[i]; b += a; }
-    return a ^ (b << 1);
+    return fmix64(h0 ^ fmix64(h1 ^ fmix64(h2 ^ fmix64(h3))));
 }
 
 static int waterfall_supported(const waterfall_t *wf) {

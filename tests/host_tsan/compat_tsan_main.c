@@ -20,6 +20,7 @@
 /* ---- stand-in for the GPU half ------------------------------------------------------------------ */
 struct ft8gpu_ctx { ft8gpu_params p; long calls; int alive; };
 static int g_created, g_destroyed;                       /* touched under ft8_compat.c's lock only (if it holds) */
+static int g_last_decode_n = -1, g_decode_calls;         /* `cache` mode (single-threaded): how many candidates the last launch decoded */
 
 int ft8gpu_create(ft8gpu_ctx **out, int device, int max_frames, const ft8gpu_params *params) {
     (void)device; (void)max_frames;
@@ -72,6 +73,7 @@ int ft8gpu_decode_candidates(ft8gpu_ctx *c, const uint8_t *mag, const ft8gpu_can
     (void)flags;
     if (!c->alive || nframes != 1) return -1;
     c->calls++;
+    g_last_decode_n = counts[0]; g_decode_calls++;
     for (int k = 0; k < counts[0]; k++) expected_status(mag, &cands[k], c->p.ldpc_iters, &status[k]);
     return 0;
 }
@@ -150,7 +152,88 @@ static void *worker(void *arg) {
     return NULL;
 }
 
-int main(void) {
+/* ---- `cache` mode: rewrites of the waterfall between ft8_find_sync and ft8_decode that an additive checksum misses ------ */
+/* the checksum ft8_compat.c used through round 5 (sum and sum of sums of the 64-bit words), kept here to show that the
+ * rewrites below are ones it could NOT see: the test has teeth only if they collide under it */
+static uint64_t additive_checksum_r05(const uint8_t *mag) {
+    uint64_t a = 0x9E3779B97F4A7C15ull, b = 0;
+    for (int i = 0; i < FT8GPU_MAG_ARRAY / 8; i++) { uint64_t w; memcpy(&w, mag + 8 * i, 8); a += w; b += a; }
+    return a ^ (b << 1);
+}
+static uint64_t plain_sum(const uint8_t *mag) {
+    uint64_t a = 0;
+    for (int i = 0; i < FT8GPU_MAG_ARRAY / 8; i++) { uint64_t w; memcpy(&w, mag + 8 * i, 8); a += w; }
+    return a;
+}
+
+static int check_decode(const waterfall_t *wf, const candidate_t *cand, int iters, const char *what) {
+    message_t msg;
+    decode_status_t st;
+    ft8gpu_decode_status want;
+    ft8gpu_candidate c1;
+    memset(&msg, 0, sizeof msg);
+    memcpy(&c1, cand, sizeof c1);
+    const bool ok = ft8_decode(wf, cand, &msg, iters, &st);
+    expected_status(wf->mag, &c1, iters, &want);
+    if (ok != (want.ok != 0) || st.ldpc_errors != want.ldpc_errors || st.crc_extracted != want.crc_extracted ||
+        st.crc_calculated != want.crc_calculated || (ok && strcmp(msg.text, want.text))) {
+        printf("cache: %s: ft8_decode answered for other bytes than the ones it was handed\n", what);
+        return 1;
+    }
+    return 0;
+}
+
+static int cache_mode(void) {
+    uint8_t *mag = malloc(FT8GPU_MAG_ARRAY + 8);
+    if (!mag) return 1;
+    int bad = 0;
+    for (int trial = 0; trial < 64; trial++) {
+        uint8_t *m = mag + (trial & 1 ? 3 : 0);            /* aligned and unaligned buffers */
+        waterfall_t wf = { .num_blocks = 92, .num_bins = 256, .time_osr = 2, .freq_osr = 2, .mag = m, .block_stride = 1024, .protocol = PROTO_FT8 };
+        fill_mag(m, 777u + (unsigned)trial);
+        if (m[0] == m[7976]) m[7976] ^= 0x5A;              /* the two bytes that will change places differ */
+        candidate_t heap[32];
+        const int n = ft8_find_sync(&wf, 24, heap, 10);
+        if (n < 3) { printf("cache: list too short\n"); bad++; continue; }
+        bad += check_decode(&wf, &heap[0], 20, "first call");
+        if (g_last_decode_n != n) { printf("cache: the first ft8_decode did not decode the whole list (%d of %d)\n", g_last_decode_n, n); bad++; }
+        int calls = g_decode_calls;
+        bad += check_decode(&wf, &heap[1], 20, "lookup");
+        if (g_decode_calls != calls) { printf("cache: an unchanged waterfall was decoded again\n"); bad++; }
+        const uint32_t before = mag_digest(m);
+        const uint64_t add_before = additive_checksum_r05(m), sum_before = plain_sum(m);
+        if (trial % 2 == 0) {
+            /* two bytes of the same lane of two 64-bit words change places (offsets 0 and 997*8, both seen by the stand-in's digest):
+             * the sum of the words, hence every byte-lane sum, is unchanged */
+            const uint64_t s0 = plain_sum(m);
+            const uint8_t t = m[0]; m[0] = m[7976]; m[7976] = t;
+            if (plain_sum(m) != s0) { printf("cache: harness error: the swap changed the word sum\n"); bad++; }
+        } else {
+            /* w[0] += d, w[1] -= 2d, w[2] += d: keeps the sum AND the sum of sums -- a collision of the round-5 checksum by construction */
+            uint64_t w[3];
+            memcpy(w, m, sizeof w);
+            const uint64_t d = 1 + (uint64_t)trial;
+            w[0] += d; w[1] -= 2 * d; w[2] += d;
+            memcpy(m, w, sizeof w);
+            if (additive_checksum_r05(m) != add_before || plain_sum(m) != sum_before) { printf("cache: harness error: the pattern does not collide\n"); bad++; }
+        }
+        if (mag_digest(m) == before) { printf("cache: harness error: rewrite invisible to the stand-in\n"); bad++; continue; }
+        calls = g_decode_calls;
+        bad += check_decode(&wf, &heap[2], 20, "after the rewrite");
+        if (g_decode_calls != calls + 1 || g_last_decode_n != 1) {
+            printf("cache: trial %d: a rewritten waterfall was answered from the remembered list (launches %d, candidates %d)\n", trial,
+                   g_decode_calls - calls, g_last_decode_n);
+            bad++;
+        }
+    }
+    freeFFTW();
+    free(mag);
+    printf("compat_cache %s: %d wrong\n", bad ? "FAILED" : "ok", bad);
+    return bad ? 1 : 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc > 1 && !strcmp(argv[1], "cache")) return cache_mode();
     pthread_t th[kThreads];
     for (int i = 0; i < kThreads; i++) pthread_create(&th[i], NULL, worker, (void *)(intptr_t)i);
     int bad = 0;

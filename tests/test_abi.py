@@ -41,10 +41,16 @@ def test_exports_every_declared_symbol(ft8):
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     assert sorted(ft8.ABI_SYMBOLS) == names
-    # nothing but the C ABI is exported
-    out = subprocess.check_output(["nm", "-D", "--defined-only", ft8.LIB_PATH]).decode()
-    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
-    assert exported == set(names)
+    # nothing but the C ABI is in the dynamic symbol table: EVERY defined entry of whatever type (code, weak template
+    # instantiations of libstdc++, data such as hipcc's __hip_cuid_*), not only the " T " ones -- csrc/libft8gpu.map
+    for lib_path in (ft8.LIB_PATH, ft8.LIB_PATH.replace("libft8gpu.so", "libft8gpu_ab.so")):
+        if not os.path.exists(lib_path):
+            assert lib_path != ft8.LIB_PATH
+            continue
+        out = subprocess.check_output(["nm", "-D", "--defined-only", lib_path]).decode()
+        entries = [l.split() for l in out.splitlines() if l.strip()]
+        assert sorted(e[-1] for e in entries) == names, (lib_path, sorted(set(e[-1] for e in entries) ^ set(names)))
+        assert {e[-2] for e in entries} == {"T"}, [e for e in entries if e[-2] != "T"]
 
 
 def test_struct_layouts(ft8):
@@ -214,3 +220,55 @@ def test_pure_queries_leave_the_error_state_alone(ft8):
     buf = C.create_string_buffer(64)
     assert lib.ft8gpu_overlap_reason(None, buf, 64) == -1 and b"ctx is NULL" in lib.ft8gpu_last_error()
     assert before != lib.ft8gpu_last_error()
+
+
+def test_pinned_array_close_refuses_while_views_live_and_keeps_the_buffer(ft8, monkeypatch):
+    """PinnedArray.close(): with an outside reference to `array` or to a view of it alive it raises and changes nothing
+    (the array stays usable, the memory stays allocated); with none it frees exactly once.  A collected object whose
+    views are alive warns (ResourceWarning) instead of failing silently.  The allocator is stubbed with malloc: the
+    real one needs a GPU (tests/test_gpu_multi.py runs it)."""
+    import gc
+    import warnings
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p; libc.malloc.argtypes = [C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
+    freed = []
+
+    class Stub:
+        @staticmethod
+        def ft8gpu_host_alloc(n):
+            return libc.malloc(n)
+
+        @staticmethod
+        def ft8gpu_host_free(p):
+            freed.append(p.value)
+
+    monkeypatch.setattr(ft8, "load_library", lambda: Stub)
+    pa = ft8.PinnedArray((4, 8), np.float32)
+    ptr = pa.ptr
+    pa.array[...] = 3.0
+    view = pa.array[1:3]
+    with pytest.raises(ft8.Ft8GpuError, match="still alive"):
+        pa.close()
+    assert pa.array is not None and pa.ptr == ptr and not freed and float(pa.array.sum()) == 96.0
+    del view
+    whole = pa.array                                     # a second name for the array itself is a live reference too
+    with pytest.raises(ft8.Ft8GpuError, match="still alive"):
+        pa.close()
+    del whole
+    pa.close()
+    assert freed == [ptr] and pa.array is None and pa.ptr is None
+    pa.close()                                            # idempotent
+    assert freed == [ptr]
+    # 1-D shape (reshape returns another view object as well) and collection with a live view
+    pb = ft8.PinnedArray((16,), np.uint8)
+    keep = pb.array[:4]
+    ptr_b = pb.ptr
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        del pb
+        gc.collect()
+    assert any(issubclass(x.category, ResourceWarning) and "NOT freed" in str(x.message) for x in w), [str(x.message) for x in w]
+    assert freed == [ptr]
+    del keep
+    libc.free(ptr); libc.free(ptr_b)

@@ -107,3 +107,31 @@ def test_compat_global_context_and_candidate_cache_under_tsan(tmp_path):
     exe = _build_compat_tsan(tmp_path, str(mutant), "compat_tsan_mutant")
     out = subprocess.run([exe], env=dict(os.environ, **TSAN_ENV), capture_output=True, text=True, timeout=600)
     assert "WARNING: ThreadSanitizer: data race" in out.stderr, "the unlocked mutant went unnoticed"
+
+
+def test_candidate_cache_sees_rewrites_an_additive_checksum_misses(tmp_path):
+    """csrc/ft8_compat.c, ft8_lib level (rtlsdr_ft8d.c:1450 -> :1476): between ft8_find_sync and ft8_decode the caller
+    rewrites the waterfall in place so that a sum (same-lane byte swap) or a sum AND sum of sums (+d, -2d, +d over three
+    words) of the 64-bit words is unchanged.  The remembered list must not answer: one-candidate launch, the new bytes'
+    status.  A mutant with the round-5 additive checksum in place of the multiply-mix hash must FAIL the same harness."""
+    compat = os.path.join(ROOT, "rtlsdr_ft8d_amd", "csrc", "ft8_compat.c")
+
+    def build(source, name):
+        exe = str(tmp_path / name)
+        subprocess.check_call(["gcc", "-O1", "-g", "-std=gnu17", "-ffp-contract=off", "-Wall", "-Wextra", "-I" + os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tests", "host_tsan", "compat_tsan_main.c"), source,
+                               os.path.join(ROOT, "rtlsdr_ft8d_amd", "csrc", "ft8_pack.c"), "-lpthread", "-lm", "-o", exe])
+        return exe
+
+    out = subprocess.run([build(compat, "compat_cache"), "cache"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "compat_cache ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    src = open(compat).read()
+    a = src.index("static uint64_t waterfall_checksum(const uint8_t *mag) {")
+    b = src.index("static int waterfall_supported(")
+    additive = ("static uint64_t waterfall_checksum(const uint8_t *mag) {\n    uint64_t a = 0x9E3779B97F4A7C15ull, b = 0;\n"
+                "    for (int i = 0; i < FT8GPU_MAG_ARRAY / 8; i++) { uint64_t w; memcpy(&w, mag + 8 * i, 8); a += w; b += a; }\n"
+                "    (void)fmix64; (void)rotl64;\n    return a ^ (b << 1);\n}\n\n")
+    mutant = tmp_path / "ft8_compat_additive.c"
+    mutant.write_text((src[:a] + additive + src[b:]).replace('"../../include/', '"' + os.path.join(ROOT, "include") + "/"))
+    out = subprocess.run([build(str(mutant), "compat_cache_additive"), "cache"], capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "answered from the remembered list" in out.stdout, "the additive-checksum mutant went unnoticed"
