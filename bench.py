@@ -97,6 +97,20 @@ def parse_args(argv=None):
                     help="run on the A/B build libft8gpu_ab.so (product kernels + the alternative kernel forms; `make -C rtlsdr_ft8d_amd/csrc ab`): "
                          "profiling of the non-product forms only, reported in the line")
     ap.add_argument("--shards", type=int, default=8, help="configs[3] on one GPU: number of contexts / shards")
+    ap.add_argument("--sustain-seconds", type=float, default=0.0,
+                    help="after the timed K steps (the headline, unchanged) keep running the same step loop for about this many seconds and add a "
+                         "`sustained` object to the line: rate, per-step p50 / p99, first-second against last-second rate, shader clock, socket power and "
+                         "temperatures over time (the headline is an 80 ms window on a power-limited kernel; this is the operating regime of a replay job)")
+    ap.add_argument("--dist-timeout", type=float, default=180.0,
+                    help="multi-rank runs: seconds any one phase (process-group init, first collective, ...) may take before the rank's watchdog "
+                         "process reports the rank and phase in a JSON line and kills the rank; also the process group's own timeout")
+    ap.add_argument("--no-exchange", action="store_true",
+                    help="multi-rank control leg: the ranks decode their shards with NO collective in the step (barrier and timing reduction only), so "
+                         "that a scaling curve separates decode scaling from the cost of the spot gather")
+    ap.add_argument("--test-hang", default=None, metavar="RANK:PHASE",
+                    help="test hook: that rank sleeps forever when it enters that phase (what a hung RCCL init looks like to the watchdog)")
+    ap.add_argument("--test-fail-exchange", default=None, metavar="RANK:STEP",
+                    help="test hook: that rank's exchange raises at that step (what a failing collective looks like to the error path)")
     ap.add_argument("--traffic", choices=("cq", "mixed"), default="cq",
                     help="message pool of the synthetic frames: cq = 'CQ call grid' only (SURVEY.md 8(d), the headline); mixed = what a receiver "
                          "meets on the air (workload.mixed_message_pool: about a quarter CQ calls, the rest QSO traffic of every message type, one "
@@ -130,22 +144,140 @@ def self_launch(args):
         if ln.startswith('{"metric"'):
             line = ln
     if p.returncode != 0 or line is None:
-        sys.stderr.write(p.stderr[-4000:])
+        sys.stderr.write(p.stderr[-6000:])
         sys.stderr.write(p.stdout[-2000:])
         sys.stderr.write(f"\nbench.py: the {args.gpus}-rank job failed (exit {p.returncode}, JSON line {'found' if line else 'missing'})\n")
+        for ln in p.stdout.splitlines():            # the diagnosis a failing or hanging rank (or its watchdog) left: relay every such line
+            if ln.startswith('{"metric"') and '"failed": true' in ln:
+                print(ln, flush=True)
         raise SystemExit(p.returncode or 1)
     print(line, flush=True)
     raise SystemExit(0)
 
 
-class ClockSampler:
-    """best-effort shader clock / socket power of GPU `index` while the timed region runs (sysfs, 20 ms period);
-    every field is null when the box does not expose the files to an ordinary user"""
+METRIC = "15 s FT8 frames decoded/s"
 
-    def __init__(self, index, enabled=True):
+# One small child process per rank (started before the rank imports torch or touches the GPU; never an exec of the rank itself).
+# The rank tells it "phase <name> <seconds>" on a pipe; when a phase outlives its limit -- a hung RCCL init holds no Python
+# thread the rank could rely on -- the child prints ONE JSON line naming rank and phase on the job's stdout, says the same on
+# stderr, and kills the rank, so that the launcher tears the job down with a non-zero status instead of waiting for ever.
+WATCHDOG_CODE = r"""
+import json, os, select, signal, sys, time
+rank, world, ppid, metric = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+phase, deadline, since, buf, history = "start", None, time.time(), b"", []
+while True:
+    r, _, _ = select.select([0], [], [], None if deadline is None else max(0.0, deadline - time.time()))
+    if r:
+        chunk = os.read(0, 4096)
+        if not chunk:
+            sys.exit(0)                              # the rank is gone: it finished, or died on its own and said why itself
+        buf += chunk
+        while b"\n" in buf:
+            ln, buf = buf.split(b"\n", 1)
+            w = ln.decode().split(" ")
+            if w[0] == "done":
+                sys.exit(0)
+            history.append([phase, round(time.time() - since, 2)])
+            phase, since = w[1], time.time()
+            deadline = since + float(w[2])
+    elif deadline is not None and time.time() >= deadline:
+        waited = round(time.time() - since, 1)
+        msg = {"metric": metric, "value": None, "unit": "frames/s", "n_gpus": world, "failed": True, "rank": rank, "phase": phase,
+               "error": "rank %d of %d hung in phase '%s' for %.0f s (limit %.0f s); killed by its watchdog" % (rank, world, phase, waited, deadline - since),
+               "phases_completed": history[1:], "pid": ppid}
+        sys.stdout.write(json.dumps(msg) + "\n"); sys.stdout.flush()
+        sys.stderr.write("bench.py watchdog: " + msg["error"] + "\n"); sys.stderr.flush()
+        try:
+            os.kill(ppid, signal.SIGKILL)
+        except OSError:
+            pass
+        sys.exit(3)
+"""
+
+
+class RankWatchdog:
+    def __init__(self, rank, world, enabled, default_timeout):
+        self.rank, self.default_timeout, self.p, self.current = rank, default_timeout, None, "start"
+        if enabled:
+            import subprocess
+            self.p = subprocess.Popen([sys.executable, "-c", WATCHDOG_CODE, str(rank), str(world), str(os.getpid()), METRIC], stdin=subprocess.PIPE)
+
+    def phase(self, name, timeout=None):
+        self.current = name
+        if self.p:
+            try:
+                self.p.stdin.write(f"phase {name} {timeout or self.default_timeout}\n".encode())
+                self.p.stdin.flush()
+            except OSError:
+                pass
+
+    def done(self):
+        if self.p:
+            try:
+                self.p.stdin.write(b"done\n")
+                self.p.stdin.flush()
+                self.p.stdin.close()
+            except OSError:
+                pass
+            self.p.wait(timeout=10)
+            self.p = None
+
+
+def _rank_step(spec):
+    """'R:X' test-hook argument -> (R, 'X') or None"""
+    if not spec:
+        return None
+    r, x = spec.split(":", 1)
+    return int(r), x
+
+
+def store_publish(store, key, value):
+    try:
+        store.set(key, json.dumps(value))
+    except Exception:                                        # diagnostics must never be what fails
+        pass
+
+
+def store_collect(store, prefix, world, wait_s=0.0):
+    """what the ranks published under prefix<rank> (c10d store: TCP, no RCCL involved); ranks that did not are absent"""
+    import datetime
+    res = {}
+    for r in range(world):
+        try:
+            if wait_s > 0:
+                store.wait([f"{prefix}{r}"], datetime.timedelta(seconds=wait_s))
+            elif not store.check([f"{prefix}{r}"]):
+                continue
+            res[str(r)] = json.loads(store.get(f"{prefix}{r}").decode())
+        except Exception:
+            continue
+    return res
+
+
+def failure_line(out, rank, world, phase, exc, store, extra=None):
+    """the ONE line a rank prints when it fails after start-up: what failed, where, and what is known of every rank's decode rate"""
+    txt = f"{type(exc).__name__}: {exc}"
+    is_coll = type(exc).__name__ in ("DistBackendError", "DistNetworkError", "DistStoreError", "DistError") or any(w in txt for w in ("NCCL", "RCCL", "nccl", "rccl", "collective"))
+    line = {"metric": METRIC, "value": None, "unit": "frames/s", "n_gpus": world, "failed": True, "rank": rank, "phase": phase,
+            ("rccl_error" if is_coll else "error"): txt[:2000], "config": out.get("config"), "build_id": out.get("build_id"), "backend": out.get("backend")}
+    if store is not None:
+        line["per_rank_decode_only"] = store_collect(store, "ft8/decode_only/", world)
+        line["ranks_info"] = store_collect(store, "ft8/info/", world)
+    line.update(extra or {})
+    return json.dumps(line)
+
+
+class ClockSampler:
+    """best-effort shader clock / socket power (and, with temps=True, the hwmon temperatures) of GPU `index` while a region runs
+    (sysfs, `period` seconds); every field is null when the box does not expose the files to an ordinary user"""
+
+    def __init__(self, index, enabled=True, period=0.02, temps=False):
         import glob
-        self.sclk, self.power = [], []
+        self.sclk, self.power, self.t = [], [], []
+        self.temp = {}                                   # label -> [deg C], sampled with the clock
         self.clk_file = self.pow_file = None
+        self.temp_files = {}
+        self.period = period
         try:
             if not enabled:
                 raise OSError("disabled")                                    # the box exposes every GPU of the host in sysfs: find ours by PCI address
@@ -159,6 +291,15 @@ class ClockSampler:
                     sorted(glob.glob(os.path.join(d, "hwmon/hwmon*/power1_input")))
                 self.pow_file = hw[0] if hw else None
                 self.bdf = bdf
+                if temps:
+                    for f in sorted(glob.glob(os.path.join(d, "hwmon/hwmon*/temp*_input"))):
+                        try:
+                            with open(f.replace("_input", "_label")) as lf:
+                                label = lf.read().strip()
+                        except OSError:
+                            label = os.path.basename(f).replace("_input", "")
+                        self.temp_files[label] = f
+                        self.temp[label] = []
         except (AttributeError, RuntimeError, OSError):
             pass
         self._stop = False
@@ -167,16 +308,28 @@ class ClockSampler:
     def _run(self):
         while not self._stop:
             try:
+                now = time.perf_counter()
                 with open(self.clk_file) as f:
                     for ln in f:
                         if "*" in ln:
                             self.sclk.append(float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip()))
+                            self.t.append(now)
                 if self.pow_file:
                     with open(self.pow_file) as f:
                         self.power.append(float(f.read()) * 1e-6)
+                for label, path in self.temp_files.items():
+                    try:
+                        with open(path) as f:
+                            self.temp[label].append(float(f.read()) * 1e-3)
+                    except (OSError, ValueError):
+                        self.temp[label].append(float("nan"))
             except (OSError, ValueError, IndexError):
                 return
-            time.sleep(0.02)
+            time.sleep(self.period)
+
+    def clear(self):
+        for v in (self.sclk, self.power, self.t, *self.temp.values()):
+            v.clear()
 
     def __enter__(self):
         if self.clk_file:
@@ -194,7 +347,18 @@ class ClockSampler:
         med = lambda v: round(float(np.median(v)), 1) if v else None
         return {"sclk_mhz_median": med(self.sclk), "sclk_mhz_min": round(min(self.sclk), 1) if self.sclk else None,
                 "power_w_median": med(self.power), "samples": len(self.sclk),
-                "source": f"sysfs pp_dpm_sclk / hwmon power of {getattr(self, 'bdf', None)}, 20 ms period over the timed region" if self.sclk else None}
+                "source": f"sysfs pp_dpm_sclk / hwmon power of {getattr(self, 'bdf', None)}, {self.period * 1e3:.0f} ms period over the timed region" if self.sclk else None}
+
+    def series(self, t0, nbuckets, bucket_s=1.0):
+        """per-bucket medians since t0: [{"sclk_mhz", "power_w", "temp_c": {label: v}}] (None where no sample fell)"""
+        t = np.asarray(self.t) - t0
+        k = np.floor(t / bucket_s).astype(int) if len(t) else np.zeros(0, int)
+        rows = []
+        for b in range(nbuckets):
+            m = k == b
+            pick = lambda v: round(float(np.nanmedian(np.asarray(v)[:len(m)][m[:len(v)]])), 1) if len(v) and m[:len(v)].any() else None
+            rows.append({"sclk_mhz": pick(self.sclk), "power_w": pick(self.power), "temp_c": {lb: pick(v) for lb, v in self.temp.items()}})
+        return rows
 
 
 def dry_records(lo, hi, step):
@@ -205,28 +369,38 @@ def dry_records(lo, hi, step):
     return rec, cnt
 
 
-def run_dry(args, out, rank, world, B, total, lo, hi):
+def run_dry(args, out, rank, world, B, total, lo, hi, store=None):
     """--dry: launcher + shard_range + SpotExchange on CPU tensors (gloo).  No decode, no GPU: `value` is not a
     decode rate and the line says so."""
     import torch
     import torch.distributed as dist
     from rtlsdr_ft8d_amd import workload
-    exch = workload.SpotExchange(B, world, torch.device("cpu"), collective=world > 1)
+    exchange = world > 1 and not args.no_exchange
+    exch = workload.SpotExchange(B, world, torch.device("cpu"), collective=exchange)
     steps = args.warmup + args.steps
+    fail = _rank_step(args.test_fail_exchange)
     ok = True
+    # what the GPU path publishes as a rank's decode-only rate before its first collective (here: the pattern fill)
+    t = time.perf_counter()
+    for k in range(3):
+        dry_records(lo, hi, k)
+    if store is not None:
+        store_publish(store, f"ft8/decode_only/{rank}", {"frames_per_s": round(3 * B / max(time.perf_counter() - t, 1e-9), 1), "what": "dry-run pattern fill"})
     t0 = time.perf_counter()
     for k in range(steps):
         s_buf, n_buf = exch.buffers(k)
         rec, cnt = dry_records(lo, hi, k)
         s_buf.copy_(torch.from_numpy(rec))
         n_buf.copy_(torch.from_numpy(cnt))
+        if fail and fail == (rank, str(k)):
+            raise RuntimeError(f"simulated collective failure at step {k} (--test-fail-exchange)")
         exch.launch(k)
         if k >= 1:                                   # check the previous step's gather while this one is in flight
             gs, gc = exch.gathered(k - 1)
-            er, ec = dry_records(0, total, k - 1)
+            er, ec = dry_records(0, total, k - 1) if exchange else dry_records(lo, hi, k - 1)
             ok = ok and bool((gs.numpy() == er).all()) and bool((gc.numpy() == ec).all())
     gs, gc = exch.gathered(steps - 1)
-    er, ec = dry_records(0, total, steps - 1)
+    er, ec = dry_records(0, total, steps - 1) if exchange else dry_records(lo, hi, steps - 1)
     ok = ok and bool((gs.numpy() == er).all()) and bool((gc.numpy() == ec).all())
     exch.wait_all()
     if world > 1:
@@ -239,8 +413,89 @@ def run_dry(args, out, rank, world, B, total, lo, hi):
     out["ms_per_step"] = round(1e3 * elapsed / steps, 3)
     out["data"] = "dry-run: no decode, pattern records through the real launcher / sharding / exchange"
     out["dry"] = True
+    out["exchange"] = "all_gather_into_tensor per step" if exchange else "none"
     out["dry_gather_identical_on_all_ranks"] = ok
     return ok
+
+
+def rank_info(torch, local_rank, gpu):
+    """what first contact needs to know about a rank: which physical GPU it holds and what the process sees"""
+    import socket
+    info = {"pid": os.getpid(), "host": socket.gethostname(), "local_rank": local_rank,
+            "env": {k: os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "HSA_ENABLE_IPC_MODE_LEGACY") if os.environ.get(k) is not None}}
+    if gpu:
+        try:
+            pr = torch.cuda.get_device_properties(local_rank)
+            info.update({"visible_devices": torch.cuda.device_count(), "device": pr.name,
+                         "pci": f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"})
+        except (AttributeError, RuntimeError):
+            pass
+        try:
+            info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            info["rccl_version"] = None
+    return info
+
+
+def run_sustained(args, torch, dist, step, fence, stream, local_rank, n_steps, B, world, use_dist, dev, headline_ms):
+    """--sustain-seconds: the SAME step loop as the timed region, for n_steps (the same number on every rank: the exchange
+    is a collective), without ever letting the GPU run dry: steps are enqueued a chunk ahead while the previous chunk's
+    hipEvents are read.  Returns the `sustained` object (rank 0's GPU; frames_per_s is the whole job)."""
+    CH = 64
+    ring = [torch.cuda.Event(enable_timing=True) for _ in range(3 * CH)]
+    start_ev = torch.cuda.Event(enable_timing=True)
+    done_ms = np.zeros(n_steps)                       # completion time of every step since the start event
+
+    def read(c0, c1):
+        ring[(c1 - 1) % len(ring)].synchronize()
+        for i in range(c0, c1):
+            done_ms[i] = start_ev.elapsed_time(ring[i % len(ring)])
+
+    with ClockSampler(local_rank, not args.no_clock_sampler, period=0.1, temps=True) as clk:
+        fence()
+        clk.clear()
+        t0 = time.perf_counter()
+        start_ev.record(stream)
+        for c0 in range(0, n_steps, CH):
+            c1 = min(c0 + CH, n_steps)
+            for i in range(c0, c1):
+                step()
+                ring[i % len(ring)].record(stream)
+            if c0 > 0:
+                read(c0 - CH, c0)                     # the chunk before this one, while this one runs
+        read((n_steps - 1) // CH * CH, n_steps)
+        fence()
+        wall = time.perf_counter() - t0
+    tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    wall_all = float(tmax.item())
+    per_step = np.diff(np.concatenate([[0.0], done_ms]))
+    nsec = max(1, int(np.ceil(done_ms[-1] / 1e3)))
+    sec = np.minimum((done_ms / 1e3).astype(int), nsec - 1)
+    full = int(done_ms[-1] // 1e3)                    # complete seconds
+    counts = np.bincount(sec, minlength=nsec)
+    rate = [int(c) * B * world for c in counts]        # frames/s of the whole job by rank 0's clock (ranks run the same steps)
+    trace = clk.series(t0, nsec)
+    pct = lambda q: round(float(np.percentile(per_step, q)), 4)
+    first, last = (rate[0], rate[full - 1]) if full >= 2 else (None, None)
+    col = lambda key: [r[key] for r in trace if r[key] is not None]
+    sclk, power = col("sclk_mhz"), col("power_w")
+    temps = {lb: [r["temp_c"][lb] for r in trace if r["temp_c"].get(lb) is not None] for lb in (trace[0]["temp_c"] if trace else {})}
+    stride = max(1, nsec // 60)
+    return {
+        "seconds": round(wall_all, 2), "steps": n_steps, "frames_per_s": round(B * world * n_steps / wall_all, 1),
+        "ms_per_step": {"mean": round(1e3 * wall_all / n_steps, 4), "p50": pct(50), "p99": pct(99), "max": round(float(per_step.max()), 4), "min": round(float(per_step.min()), 4)},
+        "headline_ms_per_step": round(headline_ms, 4), "sustained_vs_headline": round(headline_ms / (1e3 * wall_all / n_steps), 4),
+        "first_second_frames_per_s": first, "last_second_frames_per_s": last,
+        "last_vs_first_second": round(last / first, 4) if first else None,
+        "sclk_mhz": {"min": min(sclk), "median": round(float(np.median(sclk)), 1), "first_second": sclk[0], "last_second": sclk[-1]} if sclk else None,
+        "power_w": {"median": round(float(np.median(power)), 1), "max": max(power), "first_second": power[0], "last_second": power[-1]} if power else None,
+        "temperature_c": {lb: {"first_second": v[0], "last_second": v[-1], "max": max(v)} for lb, v in temps.items() if v} or None,
+        "per_second": [{"t": k, "frames_per_s": rate[k], **trace[k]} for k in range(0, full, stride)],
+        "note": "same step loop as the timed region, run back to back (hipEvent per step, read a chunk behind so the queue never drains); per-second rows: "
+                "steps completed in that second x frames, medians of the 100 ms sysfs samples of rank 0's GPU",
+    }
 
 
 def main():
@@ -256,14 +511,26 @@ def main():
     if args.traffic == "mixed":
         label = label.replace("CQ signals/frame", "signals/frame of MIXED traffic (not the headline recipe: ~22 % CQ calls, QSO messages of every type, duplicates)")
 
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    use_dist = world > 1 or args.force_dist
+    # the watchdog child exists before this process imports torch or touches the GPU (multi-rank / forced-dist runs only)
+    wd = RankWatchdog(rank, world, use_dist, args.dist_timeout)
+    hang = _rank_step(args.test_hang)
+
+    def enter(phase, timeout=None):
+        wd.phase(phase, timeout)
+        if hang and hang == (rank, phase):
+            time.sleep(10 ** 7)                  # test hook: what a rank stuck inside a library call looks like from outside
+
+    enter("import_torch", max(args.dist_timeout, 600.0))        # the first import on a fresh box pages the image in: minutes
+    import datetime
     import torch
     import torch.distributed as dist
     import rtlsdr_ft8d_amd as ft8
     from rtlsdr_ft8d_amd import workload
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch as `python bench.py --gpus {args.gpus}` (self-launching) "
                          f"or through torch.distributed.run with --nproc-per-node {args.gpus}")
@@ -271,32 +538,66 @@ def main():
         raise SystemExit("--config 1 (CPU LDPC) is a single-GPU configuration")
     if args.backend == "gloo" and not args.dry:
         raise SystemExit("--backend gloo is only meaningful with --dry (the product path has no CPU form)")
-    use_dist = world > 1 or args.force_dist
     total = B * world
     lo, hi = workload.shard_range(total, rank, world)
     assert hi - lo == B
     out = {
-        "metric": "15 s FT8 frames decoded/s", "value": None, "unit": "frames/s", "n_gpus": world,
+        "metric": METRIC, "value": None, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": label, "frames_per_gpu": B, "global_frames": total, "parallelism": f"frame-sharded x{world}"},
     }
+    pg_timeout = datetime.timedelta(seconds=args.dist_timeout)
+    ctl = {"store": None}                        # the process group's c10d store once it exists: rank diagnostics travel through it, not through RCCL
+
+    def default_store():
+        try:
+            from torch.distributed import distributed_c10d
+            return distributed_c10d._get_default_store()
+        except Exception:
+            return None
+
+    def die(exc, extra=None):
+        """a rank that fails after start-up leaves ONE diagnosable JSON line and a non-zero status; no clean shutdown of a broken group"""
+        import traceback
+        traceback.print_exc()
+        print(failure_line(out, rank, world, wd.current, exc, ctl["store"], extra), flush=True)
+        wd.done()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(4)
 
     if args.dry:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(free_port()) if world == 1 else "29533")
-        if world > 1:
-            dist.init_process_group(args.backend if args.backend == "gloo" else "gloo", rank=rank, world_size=world)
-            out["rccl_ranks"] = None
-            out["backend"] = "gloo"
-            out["ranks"] = dist.get_world_size()
-        ok = run_dry(args, out, rank, world, B, total, lo, hi)
-        if world > 1:
-            dist.destroy_process_group()
+        try:
+            if world > 1:
+                enter("init_process_group")
+                dist.init_process_group(args.backend if args.backend == "gloo" else "gloo", rank=rank, world_size=world, timeout=pg_timeout)
+                ctl["store"] = default_store()
+                out["rccl_ranks"] = None
+                out["backend"] = "gloo"
+                out["ranks"] = dist.get_world_size()
+                enter("rank_info")
+                if ctl["store"] is not None:
+                    store_publish(ctl["store"], f"ft8/info/{rank}", rank_info(torch, local_rank, False))
+            enter("exchange_steps")
+            ok = run_dry(args, out, rank, world, B, total, lo, hi, ctl["store"])
+            if world > 1 and rank == 0 and ctl["store"] is not None:
+                out["ranks_info"] = store_collect(ctl["store"], "ft8/info/", world, wait_s=10.0)
+                out["per_rank_decode_only"] = store_collect(ctl["store"], "ft8/decode_only/", world, wait_s=10.0)
+            enter("shutdown")
+            if world > 1:
+                dist.barrier()                   # rank 0 has read every rank's entries before the store's host may go away
+                dist.destroy_process_group()
+        except Exception as e:                   # noqa: BLE001 -- whatever it is, say where and exit non-zero
+            die(e)
+        wd.done()
         if rank == 0:
             print(json.dumps(out), flush=True)
         raise SystemExit(0 if ok else 1)
 
+    enter("create_context")
     ndev = torch.cuda.device_count()
     if local_rank >= ndev:
         raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({ndev} visible); --gpus must not exceed the GPUs of the node")
@@ -330,13 +631,55 @@ def main():
     single_ctx = not (args.config == 3 and world == 1)
     if single_ctx and not args.ctx_last:
         dec = make_decoder()
-    if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        out["rccl_ranks"] = dist.get_world_size()          # what RCCL itself was initialised with
-        out["backend"] = dist.get_backend()
+    decode_only = None
+    if use_dist and dec is not None:
+        # Before RCCL exists: this rank's decode rate with no collective anywhere near it (frames synthesised here are the
+        # job's frames).  Should the process group or a collective fail later, every rank's figure is still known.
+        enter("decode_only_warmup")
+        try:
+            _, tones0 = workload.message_pool(traffic=args.traffic)
+            sig0, _ = workload.frame_signals(lo, B, nsig, tones0, snr_range=snr, dup_fraction=workload.MIXED_DUP_FRACTION if args.traffic == "mixed" else 0.0)
+            iq0 = torch.empty((B, 2, ft8.NSAMPLES), dtype=torch.float32, device=dev)
+            dec.synth_frames(sig0, B, nsig, 1.0, workload.SEED_BASE, iq0, first_frame=lo)
+            s0 = torch.zeros((B, 1400), dtype=torch.uint8, device=dev)
+            n0 = torch.zeros((B,), dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            for _ in range(args.prewarm + 2):
+                dec.decode_batch_dev(iq0, B, s0, n0)
+            dec.synchronize()
+            t = time.perf_counter()
+            for _ in range(5):
+                dec.decode_batch_dev(iq0, B, s0, n0)
+            dec.synchronize()
+            dt = (time.perf_counter() - t) / 5
+            decode_only = {"ms_per_step": round(1e3 * dt, 4), "frames_per_s": round(B / dt, 1), "messages_per_frame": round(float(n0.float().mean().item()), 2),
+                           "what": f"{B} frames per step on this rank's GPU, 5 steps, before the process group exists"}
+            del iq0, s0, n0
+        except Exception as e:                   # noqa: BLE001
+            die(e)
+    try:
+        if use_dist:
+            enter("init_process_group")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=pg_timeout)
+            ctl["store"] = default_store()
+            out["rccl_ranks"] = dist.get_world_size()          # what RCCL itself was initialised with
+            out["backend"] = dist.get_backend()
+            enter("rank_info")
+            if ctl["store"] is not None:
+                store_publish(ctl["store"], f"ft8/info/{rank}", rank_info(torch, local_rank, True))
+                if decode_only:
+                    store_publish(ctl["store"], f"ft8/decode_only/{rank}", decode_only)
+            enter("first_collective")                           # RCCL builds its rings / proxies on the first call, not at init
+            probe = torch.full((1,), float(rank), dtype=torch.float32, device=dev)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            if abs(float(probe.item()) - world * (world - 1) / 2) > 1e-3:
+                raise RuntimeError(f"first all-reduce returned {float(probe.item())}, expected {world * (world - 1) / 2}")
+    except Exception as e:                       # noqa: BLE001
+        die(e, {"decode_only": decode_only})
     if single_ctx and args.ctx_last:
         held = [torch.cuda.Stream(device=dev) for _ in range(6)]       # what a framework would have created by now
         for st in held:
@@ -348,6 +691,7 @@ def main():
 
     if args.config == 3 and world == 1:
         run_config3_one_gpu(args, out, B, nsig, snr, maxc, dev)
+        wd.done()
         print(json.dumps(out), flush=True)
         return
 
@@ -360,6 +704,7 @@ def main():
     torch.cuda.set_stream(coll_stream)
 
     # ---- synthetic frames, generated in HBM (not timed); global frame g is the same samples for any world size
+    enter("synth")
     _, pool_tones = workload.message_pool(traffic=args.traffic)
     sig, _ = workload.frame_signals(lo, B, nsig, pool_tones, snr_range=snr,
                                     dup_fraction=workload.MIXED_DUP_FRACTION if args.traffic == "mixed" else 0.0)
@@ -370,25 +715,33 @@ def main():
     if args.config == 1:
         run_config1(args, out, dec, iq, B, maxc, stream, dev)
         dec.close()
+        wd.done()
         print(json.dumps(out), flush=True)
         return
 
     # spot records: two buffers per rank; the exchange of step k (one asynchronous RCCL all-gather of
     # records + counts) runs under the kernels of step k + 1 and is drained inside the timed region
-    exch = workload.SpotExchange(B, world, dev, collective=use_dist)
+    exchange = use_dist and not args.no_exchange
+    exch = workload.SpotExchange(B, world, dev, collective=exchange)
+    if use_dist:
+        out["exchange"] = "one asynchronous all_gather_into_tensor of records + counts per step" if exchange else \
+            "none (--no-exchange control leg: no collective in the step; barrier + timing reduction only)"
     torch.cuda.synchronize()                            # the buffers were zero-filled on torch's stream
     spots, nres = exch.buffers(0)
     state = {"k": 0}
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    fail = _rank_step(args.test_fail_exchange)
 
     def step():
         k = state["k"]
         s_buf, n_buf = exch.buffers(k)                  # (the collective stream) waits for the exchange that last used this buffer
-        if use_dist:
+        if exchange:
             stream.wait_stream(coll_stream)             # ... and the decoder for the collective stream
         dec.decode_batch_dev(iq, B, s_buf, n_buf)
-        if use_dist:
+        if exchange:
             coll_stream.wait_stream(stream)             # the gather is ordered behind the kernels that produce the records
+        if fail and fail == (rank, str(k)):
+            raise RuntimeError(f"simulated collective failure at step {k} (--test-fail-exchange)")
         exch.launch(k)                                  # the whole job's spot list on every rank
         state["k"] = k + 1
 
@@ -398,79 +751,103 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # the clock / power sampler starts before the warm-up so that its thread start-up does not land in the first timed step
-    with ClockSampler(local_rank, not args.no_clock_sampler) as clk:
-        for _ in range(args.prewarm + args.warmup):
-            step()
-        fence()
-        dec.enable_timing(True)          # stage events are recorded on the stream, read after the fence
-        clk.sclk.clear()
-        clk.power.clear()
-        t0 = time.perf_counter()
-        step_ev[0].record(stream)
-        for i in range(args.steps):
-            step()
-            step_ev[i + 1].record(stream)   # per-step spread: decode kernels of step i (the exchange runs on RCCL's stream)
+    try:
+        # the clock / power sampler starts before the warm-up so that its thread start-up does not land in the first timed step
+        with ClockSampler(local_rank, not args.no_clock_sampler) as clk:
+            enter("warmup_with_exchange" if exchange else "warmup")
+            for _ in range(args.prewarm + args.warmup):
+                step()
+            fence()
+            enter("timed_steps", args.dist_timeout + 60.0)
+            dec.enable_timing(True)          # stage events are recorded on the stream, read after the fence
+            clk.clear()
+            t0 = time.perf_counter()
+            step_ev[0].record(stream)
+            for i in range(args.steps):
+                step()
+                step_ev[i + 1].record(stream)   # per-step spread: decode kernels of step i (the exchange runs on RCCL's stream)
+            if use_dist:
+                # where a multi-rank step's time goes: this rank's kernels are done at t_kernels; whatever the fence still
+                # waits for after that is the exposed tail of the last gathers plus the skew between the ranks (the barrier)
+                stream.synchronize()
+                t_kernels = time.perf_counter() - t0
+            fence()
+            elapsed = time.perf_counter() - t0
+        stage_avg = dec.timings()        # mean over the timed steps (ring of the last 32)
+        timed_runs = stage_avg.pop("runs")
+        dec.enable_timing(False)
+        spots, nres = exch.buffers(state["k"] - 1) if state["k"] > 0 else (spots, nres)    # the last step's local records
+        per_step = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
+
+        enter("reduce_timings")
+        my_elapsed = elapsed
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         if use_dist:
-            # where a multi-rank step's time goes: this rank's kernels are done at t_kernels; whatever the fence still
-            # waits for after that is the exposed tail of the last gathers plus the skew between the ranks (the barrier)
-            stream.synchronize()
-            t_kernels = time.perf_counter() - t0
-        fence()
-        elapsed = time.perf_counter() - t0
-    stage_avg = dec.timings()        # mean over the timed steps (ring of the last 32)
-    timed_runs = stage_avg.pop("runs")
-    dec.enable_timing(False)
-    spots, nres = exch.buffers(state["k"] - 1) if state["k"] > 0 else (spots, nres)    # the last step's local records
-    per_step = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        if use_dist:
+            # per-rank view of the same timed region (one small all-gather, after the clock): which rank is slow, whether its
+            # context runs the overlapped pipeline, how long its own kernels took and what the gather drain + barrier added
+            mine = torch.tensor([my_elapsed, t_kernels, my_elapsed - t_kernels, 1.0 if out.get("overlap") else 0.0, float(np.median(per_step))],
+                                dtype=torch.float64, device=dev)
+            every = torch.empty(world * mine.numel(), dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(every, mine)
+            every = every.view(world, -1).cpu().numpy()
+            ms = 1e3 * every[:, 0] / args.steps
+            out["ranks_detail"] = {
+                "ms_per_step": [round(float(v), 4) for v in ms], "ms_per_step_min": round(float(ms.min()), 4), "ms_per_step_max": round(float(ms.max()), 4),
+                "imbalance": round(float(ms.max() / ms.min() - 1.0), 5),
+                "kernels_done_ms_per_step": [round(1e3 * float(v) / args.steps, 4) for v in every[:, 1]],
+                "exposed_gather_drain_and_barrier_ms_total": [round(1e3 * float(v), 4) for v in every[:, 2]],
+                "overlap": [bool(v) for v in every[:, 3]], "median_step_kernels_ms": [round(float(v), 4) for v in every[:, 4]],
+                "note": "per rank, same timed region: wall per step; host time until the rank's own kernels were done; what the final fence (gather "
+                        "drain + barrier) added once, after them; ft8gpu_overlap_active of the rank's context; median hipEvent step time"}
+            if rank == 0 and ctl["store"] is not None:
+                # first-contact facts, through the c10d store (TCP): RCCL version, what each rank sees and which physical GPU it holds,
+                # and each rank's decode-only rate measured before RCCL existed (decode scaling without any collective nearby)
+                out["ranks_info"] = store_collect(ctl["store"], "ft8/info/", world, wait_s=10.0)
+                out["per_rank_decode_only"] = store_collect(ctl["store"], "ft8/decode_only/", world, wait_s=10.0)
+                rates = [v.get("frames_per_s") for v in out["per_rank_decode_only"].values() if v.get("frames_per_s")]
+                if rates:
+                    out["decode_only_frames_per_s_sum"] = round(float(sum(rates)), 1)
 
-    my_elapsed = elapsed
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
-    if use_dist:
-        # per-rank view of the same timed region (one small all-gather, after the clock): which rank is slow, whether its
-        # context runs the overlapped pipeline, how long its own kernels took and what the gather drain + barrier added
-        mine = torch.tensor([my_elapsed, t_kernels, my_elapsed - t_kernels, 1.0 if out.get("overlap") else 0.0, float(np.median(per_step))],
-                            dtype=torch.float64, device=dev)
-        every = torch.empty(world * mine.numel(), dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(every, mine)
-        every = every.view(world, -1).cpu().numpy()
-        ms = 1e3 * every[:, 0] / args.steps
-        out["ranks_detail"] = {
-            "ms_per_step": [round(float(v), 4) for v in ms], "ms_per_step_min": round(float(ms.min()), 4), "ms_per_step_max": round(float(ms.max()), 4),
-            "imbalance": round(float(ms.max() / ms.min() - 1.0), 5),
-            "kernels_done_ms_per_step": [round(1e3 * float(v) / args.steps, 4) for v in every[:, 1]],
-            "exposed_gather_drain_and_barrier_ms_total": [round(1e3 * float(v), 4) for v in every[:, 2]],
-            "overlap": [bool(v) for v in every[:, 3]], "median_step_kernels_ms": [round(float(v), 4) for v in every[:, 4]],
-            "note": "per rank, same timed region: wall per step; host time until the rank's own kernels were done; what the final fence (gather "
-                    "drain + barrier) added once, after them; ft8gpu_overlap_active of the rank's context; median hipEvent step time"}
-
-    out["value"] = round(total * args.steps / elapsed, 1)
-    out["ms_per_step"] = round(1e3 * elapsed / args.steps, 3)
-    out["step_ms"] = {"min": round(min(per_step), 4), "median": round(float(np.median(per_step)), 4), "max": round(max(per_step), 4),
-                      "slowest_step_index": int(np.argmax(per_step)),
-                      "note": "hipEvent time between consecutive steps' last kernels on rank 0's stream"}
-    out["gpu_clock"] = clk.summary()
-    pw = (out["gpu_clock"] or {}).get("power_w_median")
-    if pw:   # the LDPC kernel runs power-limited: energy per frame is the other side of frames/s (rank 0's GPU, socket power from hwmon)
-        out["gpu_clock"]["frames_per_joule"] = round((total / max(world, 1)) * args.steps / elapsed / pw, 1)
-    out["prewarm_steps"] = args.prewarm        # untimed, before the W warm-up steps (clock ramp after idle; see --prewarm)
-    out["config"]["decoded_messages_per_frame"] = round(float(nres.cpu().numpy().mean()), 2)
-    # slots the path wrote (messages whose first token starts with "CQ", rtlsdr_ft8d.c:1509-1519); the other messages are
-    # counted in n_results and leave their slot as the caller's array had it (zeros here)
-    rec = spots.view(B, ft8.MAX_MESSAGES, 28)
-    used = torch.arange(ft8.MAX_MESSAGES, device=dev)[None, :] < nres[:, None]
-    out["config"]["cq_spots_per_frame"] = round(float(((rec != 0).any(dim=2) & used).sum().item()) / B, 2)
-    if use_dist and world > 1:
-        # the gathered list of the last step must hold every rank's records in global frame order
-        gs, gc = exch.gathered(state["k"] - 1)
-        mine = bool(torch.equal(gs[lo:hi], spots)) and bool(torch.equal(gc[lo:hi], nres))
-        flag = torch.tensor([1 if mine else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        out["gathered_list_holds_every_ranks_shard"] = bool(flag.item())
-        out["config"]["gathered_messages_per_frame"] = round(float(gc.float().mean().item()), 2)
+        out["value"] = round(total * args.steps / elapsed, 1)
+        out["ms_per_step"] = round(1e3 * elapsed / args.steps, 3)
+        out["step_ms"] = {"min": round(min(per_step), 4), "median": round(float(np.median(per_step)), 4), "max": round(max(per_step), 4),
+                          "slowest_step_index": int(np.argmax(per_step)),
+                          "note": "hipEvent time between consecutive steps' last kernels on rank 0's stream"}
+        out["gpu_clock"] = clk.summary()
+        pw = (out["gpu_clock"] or {}).get("power_w_median")
+        if pw:   # the LDPC kernel runs power-limited: energy per frame is the other side of frames/s (rank 0's GPU, socket power from hwmon)
+            out["gpu_clock"]["frames_per_joule"] = round((total / max(world, 1)) * args.steps / elapsed / pw, 1)
+        out["prewarm_steps"] = args.prewarm        # untimed, before the W warm-up steps (clock ramp after idle; see --prewarm)
+        out["config"]["decoded_messages_per_frame"] = round(float(nres.cpu().numpy().mean()), 2)
+        # slots the path wrote (messages whose first token starts with "CQ", rtlsdr_ft8d.c:1509-1519); the other messages are
+        # counted in n_results and leave their slot as the caller's array had it (zeros here)
+        rec = spots.view(B, ft8.MAX_MESSAGES, 28)
+        used = torch.arange(ft8.MAX_MESSAGES, device=dev)[None, :] < nres[:, None]
+        out["config"]["cq_spots_per_frame"] = round(float(((rec != 0).any(dim=2) & used).sum().item()) / B, 2)
+        if exchange and world > 1:
+            # the gathered list of the last step must hold every rank's records in global frame order
+            gs, gc = exch.gathered(state["k"] - 1)
+            mine = bool(torch.equal(gs[lo:hi], spots)) and bool(torch.equal(gc[lo:hi], nres))
+            flag = torch.tensor([1 if mine else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            out["gathered_list_holds_every_ranks_shard"] = bool(flag.item())
+            out["config"]["gathered_messages_per_frame"] = round(float(gc.float().mean().item()), 2)
+        if args.sustain_seconds > 0:
+            # a side figure, never the headline: the same loop for S seconds (step count fixed from the all-reduced step time,
+            # so every rank runs the same number of collectives)
+            n_sus = max(64, int(np.ceil(args.sustain_seconds * 1e3 / (1e3 * elapsed / args.steps))))
+            enter("sustained", args.dist_timeout + 3.0 * args.sustain_seconds + 60.0)
+            sus = run_sustained(args, torch, dist, step, fence, stream, local_rank, n_sus, B, world, use_dist, dev, 1e3 * elapsed / args.steps)
+            if rank == 0:
+                out["sustained"] = sus
+    except Exception as e:                       # noqa: BLE001
+        if not use_dist:
+            raise
+        die(e, {"decode_only": decode_only, "steps_launched": state["k"]})
+    enter("report", max(args.dist_timeout, 600.0))
     if rank == 0:
         launches = int(stage_avg.pop("launches_per_stage", 1))
         kernels = {k: v for k, v in stage_avg.items() if k != "total_ms"}
@@ -488,7 +865,8 @@ def main():
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "hbm_frac": round(achieved / HBM_PEAK_GBPS, 5),
             "traffic": pmc.get("traffic"),
             "binding_resource": "valu-issue" if valu_bound else None,
-            "valu_busy_frac_pmc": pmc.get("valu_busy"), "valu_frac_of_fp32_peak_pmc": pmc.get("valu_frac"),
+            "valu_busy_frac_pmc": pmc.get("valu_busy"), "valu_busy_frac_pmc_raw": pmc.get("valu_busy_raw"),
+            "valu_frac_of_fp32_peak_pmc": pmc.get("valu_frac"),
             "kernel_hbm_GBps_from_traffic": pmc.get("kernel_hbm_GBps"), "pmc_from": pmc.get("pmc_from"),
             "pmc_pipeline_form": pmc.get("pmc_pipeline_form"),
             "frac_of_measured_copy_peak": round(achieved / HBM_COPY_PEAK_GBPS, 5),
@@ -512,8 +890,13 @@ def main():
             out["end_to_end"] = host_legs(dec, iq, spots, nres, B)
     dec.close()
     if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        enter("shutdown")
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:                   # noqa: BLE001 -- the numbers exist: report them, and the shutdown trouble beside them
+            out["shutdown_error"] = f"{type(e).__name__}: {e}"[:500]
+    wd.done()
     if rank == 0:
         sys.stdout.flush()
         sys.stderr.flush()
@@ -670,7 +1053,7 @@ def pmc_figures(kernel, frames, launches, ms_per_launch, config=2):
     entries of configs[1] and configs[4] sit under "config1" / "config4").  They describe the kernel sources they were
     collected on: the summary carries a hash of csrc/ and the figures are reported only while it matches the tree this
     bench runs from (and the launch size); otherwise null."""
-    none = {"traffic": None, "valu_busy": None, "valu_frac": None, "kernel_hbm_GBps": None, "pmc_from": None, "pmc_pipeline_form": None}
+    none = {"traffic": None, "valu_busy": None, "valu_busy_raw": None, "valu_frac": None, "kernel_hbm_GBps": None, "pmc_from": None, "pmc_pipeline_form": None}
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             t = json.load(f)
@@ -690,7 +1073,10 @@ def pmc_figures(kernel, frames, launches, ms_per_launch, config=2):
     per_launch = frames // launches
     traffic = int(round(e["hbm_bytes_per_frame"] * per_launch))
     insts = e.get("valu_instructions_per_frame")
-    return {"traffic": traffic, "valu_busy": e.get("valu_busy_frac"),
+    # SQ_ACTIVE_INST_VALU and SQ_BUSY_CYCLES come from two counter passes (two runs of the command): on a saturated VALU pipe the
+    # quotient can read a hair above 1.  The fraction is reported clamped to 1.0, the raw quotient beside it.
+    busy_raw = e.get("valu_busy_frac")
+    return {"traffic": traffic, "valu_busy": None if busy_raw is None else min(1.0, busy_raw), "valu_busy_raw": busy_raw,
             "valu_frac": round(insts * per_launch * 64 / (ms_per_launch * 1e-3) / FP32_VALU_PEAK, 4) if insts else None,
             "kernel_hbm_GBps": round(traffic / (ms_per_launch * 1e-3) / 1e9, 1),
             "pmc_from": f"profiles/pmc_traffic.json{'' if config == 2 else ' [config%d]' % config} @ csrc {t.get('csrc_sha')}"

@@ -209,3 +209,66 @@ def test_bench_launcher_reports_a_failing_rank():
     rc, lines, err = _run_bench("--gpus", "2", "--backend", "gloo", "--frames", "8")     # gloo without --dry is refused by every rank
     assert rc != 0 and not lines
     assert "2-rank job failed" in err
+
+
+# ---- first-contact hardening of `bench.py --gpus N`: a hanging or failing rank must leave a diagnosable
+# JSON line within the timeout and a non-zero status; exercised on gloo through the same code path the RCCL run takes
+def _failed_lines(lines):
+    return [ln for ln in lines if ln.get("failed")]
+
+
+def test_bench_hanging_rank_in_process_group_init_is_named_within_the_timeout():
+    """rank 1 never returns from init_process_group (test hook: it sleeps where RCCL's init would hang).  Its watchdog -- a
+    child process started before torch was imported, so no Python thread of the rank is needed -- names rank and phase in a
+    JSON line and kills the rank; the launcher exits non-zero well within the driver's patience."""
+    import time
+    t0 = time.time()
+    rc, lines, err = _run_bench("--gpus", "2", "--backend", "gloo", "--dry", "--frames", "16", "--steps", "2", "--warmup", "1",
+                                "--dist-timeout", "6", "--test-hang", "1:init_process_group")
+    took = time.time() - t0
+    assert rc != 0 and took < 90, (rc, took)
+    failed = _failed_lines(lines)
+    mine = [ln for ln in failed if ln["rank"] == 1]
+    assert mine and mine[0]["phase"] == "init_process_group" and "hung in phase 'init_process_group'" in mine[0]["error"], failed
+    assert mine[0]["value"] is None and mine[0]["n_gpus"] == 2
+    assert not [ln for ln in lines if not ln.get("failed")]           # no success line from a job that did not finish
+    assert "rank 1 of 2 hung in phase 'init_process_group'" in err
+
+
+def test_bench_hanging_rank_inside_the_exchange_is_named_with_its_history():
+    rc, lines, err = _run_bench("--gpus", "2", "--backend", "gloo", "--dry", "--frames", "16", "--steps", "2", "--warmup", "1",
+                                "--dist-timeout", "8", "--test-hang", "0:exchange_steps")
+    assert rc != 0
+    mine = [ln for ln in _failed_lines(lines) if ln["rank"] == 0 and ln["phase"] == "exchange_steps"]
+    assert mine, lines
+    done = [p[0] for p in mine[0]["phases_completed"]]
+    assert done[:3] == ["import_torch", "init_process_group", "rank_info"], done
+
+
+def test_bench_failing_collective_leaves_the_error_and_every_ranks_decode_rate():
+    """a collective that raises on one rank after start-up: that rank prints ONE line with `rccl_error`, the phase, and -- read
+    from the c10d store, not through the broken group -- each rank's decode-only rate and identity"""
+    rc, lines, err = _run_bench("--gpus", "3", "--backend", "gloo", "--dry", "--frames", "16", "--steps", "4", "--warmup", "1",
+                                "--dist-timeout", "30", "--test-fail-exchange", "2:2")
+    assert rc != 0
+    mine = [ln for ln in _failed_lines(lines) if ln["rank"] == 2]
+    assert mine, (lines, err[-1500:])
+    ln = mine[0]
+    assert "simulated collective failure at step 2" in ln["rccl_error"] and ln["phase"] == "exchange_steps" and ln["value"] is None
+    assert sorted(ln["per_rank_decode_only"]) == ["0", "1", "2"] and all(v["frames_per_s"] > 0 for v in ln["per_rank_decode_only"].values())
+    assert sorted(ln["ranks_info"]) == ["0", "1", "2"] and len({v["pid"] for v in ln["ranks_info"].values()}) == 3
+    assert ln["config"]["global_frames"] == 48
+
+
+def test_bench_no_exchange_control_leg_and_rank_identities_in_the_line():
+    """--no-exchange: same launcher, shards and timing reduction, no collective in the step (the control leg that separates
+    decode scaling from gather cost); the success line carries what every rank is (pid, host, what it sees)"""
+    rc, lines, err = _run_bench("--gpus", "2", "--backend", "gloo", "--dry", "--frames", "24", "--steps", "3", "--warmup", "1", "--no-exchange")
+    assert rc == 0 and len(lines) == 1, err[-1500:]
+    assert lines[0]["exchange"] == "none" and lines[0]["dry_gather_identical_on_all_ranks"] is True
+    rc, lines, err = _run_bench("--gpus", "2", "--backend", "gloo", "--dry", "--frames", "24", "--steps", "3", "--warmup", "1")
+    assert rc == 0 and len(lines) == 1, err[-1500:]
+    assert lines[0]["exchange"].startswith("all_gather")
+    info = lines[0]["ranks_info"]
+    assert sorted(info) == ["0", "1"] and info["0"]["pid"] != info["1"]["pid"] and {v["local_rank"] for v in info.values()} == {0, 1}
+    assert sorted(lines[0]["per_rank_decode_only"]) == ["0", "1"]

@@ -6,6 +6,8 @@ import hashlib
 import numpy as np
 import pytest
 
+import stage_check
+
 pytestmark = pytest.mark.gpu
 
 
@@ -86,6 +88,12 @@ def test_config3_full_batch_properties(oracle):
         assert np.array_equal(nh, n1[:hn]) and dh.tobytes() == d1[:hn].tobytes()
         # the oracle on EVERY frame of the batch (round 3 sampled 24): about 2 s of 16 host cores on the box
         rdec, rn = _oracle_all(oracle, iq)
+        # ... and every stage boundary of every frame (waterfall bytes, ordered candidate list, the status record of every
+        # candidate from both forms of the LDPC kernel): spot records alone hid a 1-ulp LLR scale through four rounds
+        first_bad = []
+        sc = stage_check.stage_boundaries_vs_oracle(ft8, oracle, dec, iq, B, 120, 10, 20, _host_threads(), first_bad=first_bad)
+    stage_check.assert_clean(sc, "configs[2], 4096 frames", first_bad)
+    assert sc["frames"] == B and sc["candidate_records"] > 100 * B
     # recall / false decodes against what was planted
     found = planted = false_calls = total_calls = 0
     for f in range(B):
@@ -144,6 +152,10 @@ def test_config5_oversubscribed_candidates(oracle):
         gdec, gn = dec.decode_batch(host_iq)
         p = oracle.default_params(10, 480, 20)
         rdec_all, rn_all = _oracle_all(oracle, iq, p)        # every one of the 1024 frames (round 3 sampled 32)
+        first_bad = []                                       # every stage boundary of every frame at cap 480 (about 400 k candidates)
+        sc = stage_check.stage_boundaries_vs_oracle(ft8, oracle, dec, iq, B, 480, 10, 20, _host_threads(), first_bad=first_bad)
+    stage_check.assert_clean(sc, "configs[4], 1024 frames at cap 480", first_bad)
+    assert sc["candidate_records"] > 90 * B and sc["frames"] == B      # about 97 candidates per frame pass min_score on this weak traffic, up to 480 in one
     assert counts.max() > 120                                # the cap of 120 would have been exceeded
     assert np.array_equal(gn, n1[sample]) and gdec.tobytes() == d1[sample].tobytes()
     _assert_frames_equal(d1, n1, rdec_all, rn_all, "configs[4], 1024 frames at cap 480")
@@ -350,3 +362,29 @@ def test_mixed_traffic_every_candidate_record_vs_oracle(oracle):
     # codewords of a type unpack77 has no branch for: LDPC and CRC pass, unpack fails, ft8_decode returns false
     refused = (st["ldpc_errors"] == 0) & (st["crc_extracted"] == st["crc_calculated"]) & (st["unpack_status"] < 0) & (np.arange(cap)[None, :] < h_counts[:, None])
     assert int(refused.sum()) >= 5 and not st["ok"][refused].any()
+
+
+@pytest.mark.parametrize("iters", [1, 5, 13, 50])
+def test_ldpc_iteration_caps_other_than_20_at_every_stage_boundary(oracle, iters):
+    """K_LDPC_ITERS is 20 in the reference (rtlsdr_ft8d.h:45) but a run-time argument of ft8_decode (rtlsdr_ft8d.c:1476) and of
+    ft8gpu_params: the iteration loop, the skipped dead update of the last iteration, the `iters` field of the record and which
+    candidates converge in time must follow upstream's bp_decode at any cap -- 768 mixed-traffic frames (the two-part pipeline),
+    whole path and every stage boundary in both kernel forms."""
+    import torch
+    import rtlsdr_ft8d_amd as ft8
+    from rtlsdr_ft8d_amd import workload
+    B, S, cap = 768, 20, 120
+    _, tones = workload.message_pool(traffic="mixed")
+    with ft8.Decoder(device=0, max_frames=B, max_candidates=cap) as dec:
+        dec.set_params(ldpc_iters=iters)
+        sig, _ = workload.frame_signals(700000 + iters * 1000, B, S, tones, snr_range=(-19.0, -2.0), dup_fraction=workload.MIXED_DUP_FRACTION)
+        iq = torch.empty((B, 2, ft8.NSAMPLES), dtype=torch.float32, device="cuda")
+        dec.synth_frames(sig, B, S, 1.0, workload.SEED_BASE + 40 + iters, iq, first_frame=700000 + iters * 1000)
+        d1, n1 = _decode_dev(ft8, dec, iq, B, fill=0xA5)
+        rdec, rn = _oracle_all(oracle, iq, oracle.default_params(10, cap, iters), fill=0xA5)
+        first_bad = []
+        sc = stage_check.stage_boundaries_vs_oracle(ft8, oracle, dec, iq, B, cap, 10, iters, _host_threads(), first_bad=first_bad)
+    _assert_frames_equal(d1, n1, rdec, rn, f"ldpc_iters {iters}")
+    stage_check.assert_clean(sc, f"ldpc_iters {iters}", first_bad)
+    # the cap really bites: fewer decodes at 1 iteration than the about 12 per frame of 20, more than none
+    assert (2 if iters == 1 else 8) * B < int(n1.sum()) < 14 * B, int(n1.sum())

@@ -256,6 +256,13 @@ def test_config4_32768_frames_eight_shards(oracle, traffic):
                     if got_n[f0 + j] != rn[j] or got[f0 + j].tobytes() != rdec[j].tobytes():
                         bad.append(f0 + j)
         assert not bad, f"{len(bad)} of {total} frames differ from the oracle, first {bad[:8]}"
+        # one shard (a context other than the first) at every stage boundary: waterfall bytes, candidate lists, the status
+        # record of every candidate in both kernel forms
+        import stage_check
+        first_bad = []
+        g = 5 if traffic == "cq" else 2
+        sc = stage_check.stage_boundaries_vs_oracle(ft8, oracle, decs[g], shards[g], B, 120, 10, 20, nt, first_bad=first_bad)
+        stage_check.assert_clean(sc, f"configs[3] shard {g} ({traffic})", first_bad)
     finally:
         for d in decs:
             d.close()
@@ -480,3 +487,45 @@ def test_context_lifecycle_does_not_leak_device_memory():
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 << 20, (free0, free1)           # torch's caching allocator may keep a block; a leak of 40 contexts would be GBs
     assert active >= 30, f"only {active} of 40 contexts found their streams running side by side"
+
+
+def _bench_cmd(*argv, timeout=600):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MASTER_PORT"] = str(_free_port())
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=timeout)
+    return p.returncode, [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith('{"metric"')], p.stderr
+
+
+def test_bench_one_rank_rccl_leg_first_contact_fields_and_sustained_run():
+    """`bench.py --force-dist` (RCCL with one rank: the N > 1 code path on one GPU) with the round-6 first-contact plumbing: the
+    watchdog's phases, the decode-only rate measured before RCCL exists, the first all-reduce, the c10d-store exchange of rank
+    identities (PCI address, RCCL version, visible devices), and a short --sustain-seconds run after the timed steps."""
+    rc, lines, err = _bench_cmd("--force-dist", "--frames", "1024", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-host-legs",
+                                "--sustain-seconds", "1.5")
+    assert rc == 0 and len(lines) == 1, err[-3000:]
+    ln = lines[0]
+    assert ln["rccl_ranks"] == 1 and ln["backend"] == "nccl" and ln["value"] > 100000
+    assert ln["exchange"].startswith("one asynchronous all_gather")
+    info = ln["ranks_info"]["0"]
+    assert info["visible_devices"] >= 1 and len(info["pci"].split(":")) == 3 and info["rccl_version"]
+    d0 = ln["per_rank_decode_only"]["0"]
+    assert d0["frames_per_s"] > 100000 and d0["messages_per_frame"] > 8
+    s = ln["sustained"]
+    assert s["steps"] >= 64 and s["frames_per_s"] > 100000 and s["ms_per_step"]["p50"] <= s["ms_per_step"]["p99"] <= s["ms_per_step"]["max"]
+    assert 0.5 < s["sustained_vs_headline"] < 1.5
+
+
+def test_bench_rank_hanging_at_its_first_collective_is_killed_and_named():
+    """the watchdog on a real GPU process: the rank stops (test hook) where RCCL's first collective would hang; the child process
+    reports rank and phase and kills it -- no re-exec, no Python thread of the rank involved"""
+    import time
+    t0 = time.time()
+    rc, lines, err = _bench_cmd("--force-dist", "--frames", "512", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-host-legs",
+                                "--dist-timeout", "10", "--test-hang", "0:first_collective")
+    assert rc != 0 and time.time() - t0 < 180
+    failed = [ln for ln in lines if ln.get("failed")]
+    assert failed and failed[0]["rank"] == 0 and failed[0]["phase"] == "first_collective", (lines, err[-2000:])
+    done = [p[0] for p in failed[0]["phases_completed"]]
+    assert "decode_only_warmup" in done and "init_process_group" in done

@@ -94,3 +94,76 @@ def test_harness_on_libft8gpu_equals_the_oracle_dump(tmp_path):
     diff = [(i, x, y) for i, (x, y) in enumerate(zip(a, b)) if x != y]
     assert len(a) == len(b) and not diff, (len(a), len(b), diff[:5])
     assert sum(" ok 1 " in ln for ln in a) > 150
+
+
+# ---- the recipe must land on the right upstream: API-era detection of tools/pin_ft8_lib.sh -----------------------------------------
+# Declaration-only fake trees written by this test (the three shapes ft8/decode.h has had upstream, as far as the reference's call
+# sites and the later public API tell): nothing of upstream's text, no bodies.
+_OLD_H = "typedef struct { int num_blocks; int num_bins; int time_osr; int freq_osr; uint8_t* mag; } waterfall_t;\n" \
+         "int find_sync(const waterfall_t* power, int num_candidates, candidate_t heap[], int min_score);\n"
+_ERA_H = "typedef struct { int max_blocks; int num_blocks; int num_bins; int time_osr; int freq_osr; uint8_t* mag; int block_stride;\n" \
+         "  ftx_protocol_t   protocol; } waterfall_t;\n" \
+         "int ft8_find_sync(const waterfall_t* power, int num_candidates, candidate_t heap[], int min_score);\n" \
+         "bool ft8_decode(const waterfall_t* power, const candidate_t* cand, message_t* message, int max_iterations, decode_status_t* status);\n"
+_NEW_H = "typedef struct { int max_blocks; int num_blocks; uint8_t* mag; int block_stride; ftx_protocol_t protocol; } ftx_waterfall_t;\n" \
+         "int ftx_find_candidates(const ftx_waterfall_t* power, int num_candidates, ftx_candidate_t heap[], int min_score);\n" \
+         "bool ftx_decode_candidate(const ftx_waterfall_t* power, const ftx_candidate_t* cand, int max_iterations, ftx_message_t* message, ftx_decode_status_t* status);\n"
+
+
+def _fake_tree(d, decode_h):
+    os.makedirs(os.path.join(d, "ft8"), exist_ok=True)
+    for name, text in (("decode.h", decode_h), ("decode.c", "/* empty */\n"), ("pack.h", "int pack77(const char* msg, uint8_t* c77);\n"),
+                       ("encode.h", "void ft8_encode(const uint8_t* payload, uint8_t* tones);\n"),
+                       ("unpack.h", "int unpack77(const uint8_t* a77, char* message);\n")):
+        with open(os.path.join(d, "ft8", name), "w") as f:
+            f.write(text)
+
+
+def _pin(up, **env):
+    p = subprocess.run(["bash", os.path.join(ROOT, "tools", "pin_ft8_lib.sh"), up], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, PIN_CHECK_ERA_ONLY="1", **env))
+    return p.returncode, p.stdout + p.stderr
+
+
+def test_pin_recipe_refuses_a_checkout_of_the_wrong_api_era(tmp_path):
+    """A maintainer with ANY ft8_lib clone gets PINNED / DIFFERENT or an instruction which revision to check out -- never a wall
+    of compiler errors.  HEAD of upstream today has the ftx_* interface; clones from before FT4 support have no waterfall_t.protocol."""
+    new, old, era = str(tmp_path / "new"), str(tmp_path / "old"), str(tmp_path / "era")
+    _fake_tree(new, _NEW_H)
+    _fake_tree(old, _OLD_H)
+    _fake_tree(era, _ERA_H)
+    rc, out = _pin(new)
+    assert rc == 3 and "REFUSED" in out and "too-new" in out and "ftx_find_candidates" in out and "rtlsdr_ft8d.c:1450" in out
+    assert "git log --reverse" in out and "not a git work tree" in out
+    rc, out = _pin(old)
+    assert rc == 3 and "too-old" in out and "predates FT4 support" in out and "rtlsdr_ft8d.c:1440-1448" in out
+    rc, out = _pin(era)
+    assert rc == 0 and "API era: ft8_find_sync / ft8_decode with waterfall_t.protocol" in out
+    rc, out = _pin(str(tmp_path / "nothing"))
+    assert rc == 2 and "not an ft8_lib checkout" in out
+
+
+def test_pin_recipe_names_the_revision_to_check_out_from_the_clones_own_history(tmp_path):
+    """with history at hand the refusal computes the window from THIS clone (pickaxe over ft8/decode.h) and prints the checkout
+    command: the parent of the commit that brought the ftx_* names"""
+    up = str(tmp_path / "clone")
+    os.makedirs(up)
+    git = lambda *a: subprocess.check_output(["git", "-C", up, "-c", "user.name=t", "-c", "user.email=t@t", *a], text=True).strip()
+    git("init", "-q")
+    shas = []
+    for h, msg in ((_OLD_H, "C port"), (_ERA_H, "FT4 support: protocol field"), (_ERA_H + "/* later fix */\n", "fix"), (_NEW_H, "rename to ftx_*"),
+                   (_NEW_H + "/* more */\n", "more")):
+        _fake_tree(up, h)
+        git("add", "-A")
+        git("commit", "-q", "-m", msg)
+        shas.append(git("rev-parse", "HEAD"))
+    rc, out = _pin(up)                                       # HEAD: the later API
+    assert rc == 3 and "too-new" in out
+    assert f"SUGGESTED: git -C {up} checkout {shas[2]}" in out, out
+    assert "FT4 support: protocol field" in out and "fix" in out
+    git("checkout", "-q", shas[0])                           # an old revision checked out: same suggestion from the full history
+    rc, out = _pin(up)
+    assert rc == 3 and "too-old" in out and f"checkout {shas[2]}" in out
+    git("checkout", "-q", shas[2])
+    rc, out = _pin(up)
+    assert rc == 0

@@ -24,14 +24,21 @@ def main():
     ap.add_argument("--vary-min-score", action="store_true",
                     help="draw K_MIN_SCORE per batch from 10, 10, 5, 0, -3, 20, 30 (the reference fixes 10, rtlsdr_ft8d.h:43; the run-time form must "
                          "follow the same rules at any threshold: at 0 and below every position of the scan survives the gate)")
+    ap.add_argument("--vary-iters", action="store_true",
+                    help="draw K_LDPC_ITERS per batch from 20, 20, 1, 5, 13, 50 on both sides (the reference fixes 20, rtlsdr_ft8d.h:45, and passes it "
+                         "at rtlsdr_ft8d.c:1476; the kernel's iteration loop, its skipped dead last update and the iteration field of the status "
+                         "record must follow upstream's bp_decode at any cap)")
     ap.add_argument("--records", "--stages", action="store_true", dest="records",
                     help="also compare every stage boundary of every frame through the stage entries: all 94 208 waterfall bytes, the ordered "
                          "candidate list, and the 48-byte status record of EVERY candidate (parity errors, iterations, packed bits, CRCs, unpack "
                          "status, text) -- the text of a message that is not a CQ call never reaches the spot records, and a deviation inside "
-                         "a candidate that does not decode reaches nothing")
+                         "a candidate that does not decode reaches nothing.  The records are taken from BOTH forms of the LDPC kernel: the stage "
+                         "entry's own (ft8_decode_kernel<true,1>, every byte) and the one the batch pipeline runs (<false,3>, FT8GPU_DBG_PIPELINE_FORM: "
+                         "every byte but ldpc_errors, which it reports as 0 / 83 and must agree on zero) -- tests/stage_check.py")
     args = ap.parse_args()
     import torch
     import oracle_lib as O
+    import stage_check
     import rtlsdr_ft8d_amd as ft8
     from rtlsdr_ft8d_amd import workload
     sys.path.insert(0, ROOT)
@@ -50,17 +57,18 @@ def main():
     spots = torch.zeros((B, 1400), dtype=torch.uint8, device="cuda")
     nres = torch.zeros((B,), dtype=torch.int32, device="cuda")
     bad = total = msgs = written = 0
-    rec_bad = rec_total = rec_ok = wf_bad_cells = wf_bad_frames = cand_bad_frames = 0
-    if args.records:
-        mag = torch.empty((B, ft8.MAG_ARRAY), dtype=torch.uint8, device="cuda")
-        counts = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    stages = stage_check.new_counters()
+    first_bad = []
+    iters_hist = {}
     t0 = time.time()
     for b in range(args.batches):
         nsig = int(rng.integers(0, 61))
         lo_snr = float(rng.uniform(-26, -10)); hi_snr = lo_snr + float(rng.uniform(2, 20))
         cap = int(rng.choice([120, 120, 120, 60, 240, 480]))
         min_score = int(rng.choice([10, 10, 5, 0, -3, 20, 30])) if args.vary_min_score else 10
-        dec.set_params(min_score=min_score, max_candidates=cap)
+        iters = int(rng.choice([20, 20, 1, 5, 13, 50])) if args.vary_iters else 20
+        iters_hist[iters] = iters_hist.get(iters, 0) + B
+        dec.set_params(min_score=min_score, max_candidates=cap, ldpc_iters=iters)
         sig, _ = workload.frame_signals(1_000_000 + (args.seed - 123) * 10_000_000 + b * B, B, nsig, tones, snr_range=(lo_snr, hi_snr),
                                         dup_fraction=workload.MIXED_DUP_FRACTION if mixed else 0.0,
                                         **(dict(f_range=(-20.0, 1620.0), dt_range=(-1.5, 3.0)) if args.edges else {}))
@@ -71,41 +79,23 @@ def main():
         dec.synchronize()
         g = spots.cpu().numpy().view(ft8.RESULT_DTYPE).reshape(B, 50)
         gn = nres.cpu().numpy()
-        rdec, rn = O.subsystem_batch(iq.cpu().numpy(), O.default_params(min_score, cap, 20), cores, decodes=start)
+        rdec, rn = O.subsystem_batch(iq.cpu().numpy(), O.default_params(min_score, cap, iters), cores, decodes=start)
         mism = [k for k in range(B) if gn[k] != rn[k] or g[k].tobytes() != rdec[k].tobytes()]
         if args.records:
-            st_c = torch.zeros((B, cap, 48), dtype=torch.uint8, device="cuda")       # [B][cap] records and candidates for this batch's cap
-            cd_c = torch.zeros((B, cap, 8), dtype=torch.uint8, device="cuda")
-            torch.cuda.synchronize()
-            dec.waterfall_dev(iq, B, mag)
-            dec.find_sync_dev(mag, B, cd_c, counts)
-            dec.decode_candidates_dev(mag, cd_c, counts, B, st_c)
-            dec.synchronize()
-            h_counts = counts.cpu().numpy()
-            h_mag = mag.cpu().numpy()
-            h_cands = cd_c.cpu().numpy().view(O.CAND_DTYPE).reshape(B, cap)
-            ref_mag = O.waterfall_batch(iq.cpu().numpy(), False, cores)                       # every byte of every waterfall
-            wdiff = (h_mag != ref_mag)
-            wf_bad_cells += int(wdiff.sum()); wf_bad_frames += int(wdiff.any(axis=1).sum())
-            ref_cands, ref_counts = O.find_sync_batch(ref_mag, cap, min_score, cores)                # the ordered candidate lists
-            cand_bad_frames += int(((h_counts != ref_counts) | (h_cands.view(np.uint64) != ref_cands.view(np.uint64)).any(axis=1)).sum())
-            want = O.decode_candidates_batch(h_mag, h_cands, h_counts, 20, cores)
-            got = st_c.cpu().numpy()
-            rb = int((got != want).any(axis=2).sum())
-            rec_bad += rb; rec_total += int(h_counts.sum()); rec_ok += int((want[:, :, 9] == 1).sum())
-            del st_c, cd_c
-            if rb:
-                print(f"batch {b}: {rb} candidate records differ", flush=True)
+            before = stage_check.differing(stages)
+            stage_check.stage_boundaries_vs_oracle(ft8, O, dec, iq, B, cap, min_score, iters, cores, counters=stages, first_bad=first_bad)
+            if stage_check.differing(stages) != before:
+                print(f"batch {b}: stage boundaries differ: {stages} first {first_bad}", flush=True)
         w = int(sum(1 for k in range(B) for j in range(min(int(gn[k]), 50)) if g[k, j].tobytes() != stale_rec)) if mixed else int(np.minimum(gn, 50).sum())
         bad += len(mism); total += B; msgs += int(gn.sum()); written += w
-        print(f"batch {b}: nsig {nsig} snr [{lo_snr:.0f},{hi_snr:.0f}] cap {cap} min_score {min_score}: {int(gn.sum())} messages, {w} CQ spots, mismatching frames {len(mism)}", flush=True)
+        print(f"batch {b}: nsig {nsig} snr [{lo_snr:.0f},{hi_snr:.0f}] cap {cap} min_score {min_score} iters {iters}: {int(gn.sum())} messages, {w} CQ spots, mismatching frames {len(mism)}", flush=True)
     print(json.dumps({"frames": total, "messages": msgs, "cq_spots_written": written, "mismatching_frames": bad, "seconds": round(time.time() - t0, 1), "seed": args.seed,
                       "batches": args.batches, "traffic": args.traffic, "edges": bool(args.edges), "vary_min_score": bool(args.vary_min_score), "initial_record_byte": fill, "messages_per_frame": round(msgs / max(total, 1), 3),
                       "cq_spots_per_frame": round(written / max(total, 1), 3), "build_id": build_id,
-                      **({"waterfall_cells_compared": total * ft8.MAG_ARRAY, "waterfall_cells_differing": wf_bad_cells, "waterfall_frames_differing": wf_bad_frames,
-                          "candidate_lists_differing": cand_bad_frames, "candidate_records_compared": rec_total, "candidate_records_decoded_ok": rec_ok,
-                          "candidate_records_differing": rec_bad} if args.records else {})}))
+                      "vary_iters": bool(args.vary_iters), "frames_by_ldpc_iters": {str(k): v for k, v in sorted(iters_hist.items())},
+                      **({"stages": stages, "stage_differences_total": stage_check.differing(stages), "first_differences": first_bad} if args.records else {})}))
+    return 1 if bad or (args.records and stage_check.differing(stages)) else 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
