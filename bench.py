@@ -1075,7 +1075,7 @@ def pmc_figures(kernel, frames, launches, ms_per_launch, config=2):
     insts = e.get("valu_instructions_per_frame")
     # SQ_ACTIVE_INST_VALU and SQ_BUSY_CYCLES come from two counter passes (two runs of the command): on a saturated VALU pipe the
     # quotient can read a hair above 1.  The fraction is reported clamped to 1.0, the raw quotient beside it.
-    busy_raw = e.get("valu_busy_frac")
+    busy_raw = e.get("valu_busy_frac_raw", e.get("valu_busy_frac"))
     return {"traffic": traffic, "valu_busy": None if busy_raw is None else min(1.0, busy_raw), "valu_busy_raw": busy_raw,
             "valu_frac": round(insts * per_launch * 64 / (ms_per_launch * 1e-3) / FP32_VALU_PEAK, 4) if insts else None,
             "kernel_hbm_GBps": round(traffic / (ms_per_launch * 1e-3) / 1e9, 1),

@@ -2,7 +2,7 @@
  * ft8_node_bench.c -- the multi-GPU path of one node driven from plain C (north_star: "host code stays C ... many
  * independent 15 s frames shard embarrassingly across the GPUs of one node with a trivial RCCL gather for the spot list").
  *
- *   ft8_node_bench [-g gpus] [-f frames_per_gpu] [-s steps] [-c signals_per_frame] [-r]
+ *   ft8_node_bench [-g gpus] [-f frames_per_gpu] [-s steps] [-c signals_per_frame] [-r] [-t phase_timeout_s]
  *
  * One context per GPU (ft8gpu_create), every GPU synthesises its own contiguous shard of the job in its HBM
  * (ft8gpu_synth_frames_at: global frame g is the same samples whatever the number of GPUs), then `steps` times:
@@ -11,12 +11,16 @@
  *   -r        every GPU decodes into its own HBM (ft8gpu_decode_batch, FT8GPU_DEVICE_PTRS) and ft8gpu_gather_spots leaves
  *             the whole job's list on EVERY GPU with one grouped RCCL all-gather per buffer over xGMI.
  * Prints one JSON line: frames/s of the whole node, messages per frame, and a checksum of the gathered list.
+ * First contact with several GPUs (RCCL's ncclCommInitAll and first grouped all-gather have never run with more than one
+ * device on the boxes this was developed on): every phase runs under alarm(-t seconds, default 180); a phase that
+ * outlives it ends the program with exit status 3 and "hung in phase '<name>'" on stderr instead of hanging a node.
  * Replaces nothing in the reference (a single decoder thread, rtlsdr_ft8d.c:221-285); it is the batch counterpart of its
  * decodeRecordedFile() loop (:859-887).  No HIP header, no C++: the C ABI of include/ft8gpu.h only.
  * Build:  gcc -O2 -std=gnu17 -Iinclude examples/ft8_node_bench.c -Lrtlsdr_ft8d_amd -lft8gpu \
  *             -Wl,-rpath,$PWD/rtlsdr_ft8d_amd -lm -o examples/ft8_node_bench
  */
 #include <math.h>
+#include <signal.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -42,6 +46,21 @@ static uint64_t rng_next(uint64_t *s) {
 }
 static double rng_unit(uint64_t *s) { return (double)(rng_next(s) >> 11) / 9007199254740992.0; }
 
+/* phase watchdog: alarm() re-armed at every phase; the handler uses async-signal-safe calls only */
+static const char *volatile g_phase = "start";
+static unsigned g_phase_timeout = 180;
+static void on_alarm(int sig) {
+    (void)sig;
+    static const char a[] = "ft8_node_bench: hung in phase '", b[] = "' (limit given by -t); exiting with status 3\n";
+    const char *p = g_phase;
+    if (write(2, a, sizeof a - 1) < 0 || write(2, p, strlen(p)) < 0 || write(2, b, sizeof b - 1) < 0) _exit(3);
+    _exit(3);
+}
+static void phase(const char *name) {
+    g_phase = name;
+    alarm(g_phase_timeout);
+}
+
 static int die(const char *what) {
     fprintf(stderr, "ft8_node_bench: %s: %s\n", what, ft8gpu_last_error());
     return 1;
@@ -49,13 +68,14 @@ static int die(const char *what) {
 
 int main(int argc, char **argv) {
     int gpus = ft8gpu_device_count(), frames = 1024, steps = 5, nsig = 20, device_gather = 0, opt;
-    while ((opt = getopt(argc, argv, "g:f:s:c:r")) != -1) {
+    while ((opt = getopt(argc, argv, "g:f:s:c:rt:")) != -1) {
         if (opt == 'g') gpus = atoi(optarg);
         else if (opt == 'f') frames = atoi(optarg);
         else if (opt == 's') steps = atoi(optarg);
         else if (opt == 'c') nsig = atoi(optarg);
         else if (opt == 'r') device_gather = 1;
-        else { fprintf(stderr, "usage: %s [-g gpus] [-f frames_per_gpu] [-s steps] [-c signals_per_frame] [-r]\n", argv[0]); return 2; }
+        else if (opt == 't') g_phase_timeout = (unsigned)atoi(optarg);
+        else { fprintf(stderr, "usage: %s [-g gpus] [-f frames_per_gpu] [-s steps] [-c signals_per_frame] [-r] [-t phase_timeout_s]\n", argv[0]); return 2; }
     }
     if (gpus < 1 || gpus > MAX_GPUS || frames < 1 || steps < 1 || nsig < 0 || nsig > 64) { fprintf(stderr, "ft8_node_bench: bad arguments (%d GPUs visible)\n", ft8gpu_device_count()); return 2; }
 
@@ -69,6 +89,8 @@ int main(int argc, char **argv) {
         ft8gpu_encode(payload, pool_tones[k]);
     }
 
+    signal(SIGALRM, on_alarm);
+    phase("create contexts + synthesise shards");
     ft8gpu_ctx *ctx[MAX_GPUS] = { 0 };
     float *iq_dev[MAX_GPUS] = { 0 };
     struct decoder_results *dec_dev[MAX_GPUS] = { 0 }, *all_dec_dev[MAX_GPUS] = { 0 };
@@ -115,6 +137,7 @@ int main(int argc, char **argv) {
     double t0 = 0.0;
     for (int s = -1; s < steps; s++) {                     /* step -1: warm-up (buffers, RCCL communicators) */
         if (s == 0) t0 = now_s();
+        phase(s < 0 ? (device_gather ? "warm-up step (ncclCommInitAll + first grouped all-gather)" : "warm-up step") : "timed steps");
         if (!device_gather) {
             if (ft8gpu_decode_batch_multi_dev(ctx, gpus, (const float *const *)iq_dev, nframes_dev, decodes, n_results)) return die("ft8gpu_decode_batch_multi_dev");
         } else {
@@ -127,6 +150,7 @@ int main(int argc, char **argv) {
         }
     }
     const double dt = now_s() - t0;
+    phase("read back + checksum");
     if (device_gather) {                                   /* every GPU holds the whole list: read it back from the LAST one */
         if (ft8gpu_memcpy_d2h(ctx[gpus - 1], decodes, all_dec_dev[gpus - 1], total * rec_bytes)) return die("ft8gpu_memcpy_d2h");
         if (ft8gpu_memcpy_d2h(ctx[gpus - 1], n_results, all_n_dev[gpus - 1], total * sizeof(int32_t))) return die("ft8gpu_memcpy_d2h");
@@ -150,9 +174,11 @@ int main(int argc, char **argv) {
         ft8gpu_dev_free(ctx[g], iq_dev[g]);
         if (device_gather) { ft8gpu_dev_free(ctx[g], dec_dev[g]); ft8gpu_dev_free(ctx[g], n_dev[g]); ft8gpu_dev_free(ctx[g], all_dec_dev[g]); ft8gpu_dev_free(ctx[g], all_n_dev[g]); }
     }
+    phase("shutdown");
     if (device_gather) ft8gpu_gather_shutdown();
     for (int g = 0; g < gpus; g++) ft8gpu_destroy(ctx[g]);
     ft8gpu_host_free(decodes);
     ft8gpu_host_free(n_results);
+    alarm(0);
     return 0;
 }

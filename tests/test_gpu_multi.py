@@ -529,3 +529,55 @@ def test_bench_rank_hanging_at_its_first_collective_is_killed_and_named():
     assert failed and failed[0]["rank"] == 0 and failed[0]["phase"] == "first_collective", (lines, err[-2000:])
     done = [p[0] for p in failed[0]["phases_completed"]]
     assert "decode_only_warmup" in done and "init_process_group" in done
+
+
+def test_failed_buffer_growth_leaves_the_context_as_it_was():
+    """ft8gpu_set_params growing the candidate cap under memory pressure: with the GPU's memory nearly full the
+    second of the two new buffers cannot be allocated -- the call must fail with a message, free what it got, and leave the
+    context on its old buffers and old cap: the same frames decode to the same records afterwards, and the growth succeeds
+    once memory is there again.  (Before: both old buffers were freed first, a failed growth left NULL pointers behind.)"""
+    import torch
+    import rtlsdr_ft8d_amd as ft8
+    from rtlsdr_ft8d_amd import workload
+    F, n = 32768, 64
+    with ft8.Decoder(device=0, max_frames=F, max_candidates=120) as dec:
+        iq = _job(ft8, workload, dec, 910000, n)
+        spots = torch.zeros((n, 1400), dtype=torch.uint8, device="cuda")
+        nres = torch.zeros((n,), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        dec.decode_batch_dev(iq, n, spots, nres)
+        dec.synchronize()
+        before = (spots.cpu().numpy().tobytes(), nres.cpu().numpy().tobytes())
+        need_status = F * 1024 * 48                              # 1.6 GB: the second buffer of the growth to cap 1024 (the first is 268 MB)
+        free, _ = torch.cuda.mem_get_info()
+        filler, left = [], free - (need_status - (256 << 20))    # leave less than the second buffer needs, more than the first
+        while left > (64 << 20):
+            sz = min(left, 8 << 30)
+            try:
+                filler.append(torch.empty(sz, dtype=torch.uint8, device="cuda"))
+                left -= sz
+            except torch.OutOfMemoryError:
+                break
+        free_now, _ = torch.cuda.mem_get_info()
+        assert free_now < need_status, (free_now, need_status)
+        with pytest.raises(ft8.Ft8GpuError, match="out of device memory"):
+            dec.set_params(max_candidates=1024)
+        assert dec.max_candidates == 120
+        free_after, _ = torch.cuda.mem_get_info()
+        assert free_after >= free_now - (8 << 20)                # the first new buffer was given back
+        spots.zero_(); nres.zero_()
+        torch.cuda.synchronize()
+        dec.decode_batch_dev(iq, n, spots, nres)                 # old buffers, old cap: same records
+        dec.synchronize()
+        assert (spots.cpu().numpy().tobytes(), nres.cpu().numpy().tobytes()) == before
+        del filler
+        torch.cuda.empty_cache()
+        dec.set_params(max_candidates=1024)                      # memory is back: the growth goes through
+        assert dec.max_candidates == 1024
+        dec.set_params(max_candidates=120)
+        spots.zero_(); nres.zero_()
+        torch.cuda.synchronize()
+        dec.decode_batch_dev(iq, n, spots, nres)
+        dec.synchronize()
+        assert (spots.cpu().numpy().tobytes(), nres.cpu().numpy().tobytes()) == before
+        assert int(nres.sum().item()) > 8 * n

@@ -89,7 +89,11 @@ def main():
                     "write_bytes_per_frame": round(w / frames, 1)}
             if "SQ_ACTIVE_INST_VALU" in v and "GRBM_GUI_ACTIVE" in v:
                 # SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves; GRBM_GUI_ACTIVE is summed over the 8 XCDs
-                t[k]["valu_busy_frac"] = round(v["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * v["GRBM_GUI_ACTIVE"] / 8), 3)
+                # The two counters come from different passes (= different runs of the command), so on a saturated pipe the quotient
+                # can read a hair above 1: the fraction is stored clamped, the raw quotient beside it.
+                raw = round(v["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * v["GRBM_GUI_ACTIVE"] / 8), 3)
+                t[k]["valu_busy_frac"] = min(1.0, raw)
+                t[k]["valu_busy_frac_raw"] = raw
             for cn in ("SQ_INSTS_VALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
                 if cn in v:
                     t[k][cn] = v[cn]
