@@ -58,8 +58,8 @@ if [ "$era" != ok ]; then
     echo "      git log --reverse --format='%h %ad %s' --date=short -G'ftx_protocol_t[[:space:]]+protocol' -- ft8/decode.h | head -1    # first commit inside"
     echo "      git log --reverse --format='%h %ad %s' --date=short -G'ftx_find_candidates' -- ft8/decode.h | head -1                  # first commit outside (take its parent)"
     if git -C "$UP" rev-parse --git-dir >/dev/null 2>&1; then
-        first_in=$(git -C "$UP" log --all --reverse --format=%H -G'ftx_protocol_t[[:space:]]+protocol' -- ft8/decode.h 2>/dev/null | head -1)
-        first_out=$(git -C "$UP" log --all --reverse --format=%H -G'ftx_find_candidates' -- ft8/decode.h 2>/dev/null | head -1)
+        first_in=$(git -C "$UP" log --all --reverse --format=%H -G'ftx_protocol_t[[:space:]]+protocol' -- ft8/decode.h 2>/dev/null | sed -n 1p)      # (sed reads to the end: no SIGPIPE under pipefail)
+        first_out=$(git -C "$UP" log --all --reverse --format=%H -G'ftx_find_candidates' -- ft8/decode.h 2>/dev/null | sed -n 1p)
         if [ -n "$first_in" ]; then
             echo "  This clone's history: first commit inside the window  $(git -C "$UP" log -1 --format='%h %ad %s' --date=short "$first_in")"
             if [ -n "$first_out" ] && git -C "$UP" rev-parse -q --verify "$first_out~1" >/dev/null; then
