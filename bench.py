@@ -483,6 +483,12 @@ def run_sustained(args, torch, dist, step, fence, stream, local_rank, n_steps, B
     sclk, power = col("sclk_mhz"), col("power_w")
     temps = {lb: [r["temp_c"][lb] for r in trace if r["temp_c"].get(lb) is not None] for lb in (trace[0]["temp_c"] if trace else {})}
     stride = max(1, nsec // 60)
+    # the first three seconds in 100 ms buckets: how long the clock takes to settle after whatever preceded the run
+    early = []
+    for b in range(30):
+        m = (done_ms >= 100.0 * b) & (done_ms < 100.0 * (b + 1))
+        if m.any():
+            early.append(round(float(per_step[m].mean()), 4))
     return {
         "seconds": round(wall_all, 2), "steps": n_steps, "frames_per_s": round(B * world * n_steps / wall_all, 1),
         "ms_per_step": {"mean": round(1e3 * wall_all / n_steps, 4), "p50": pct(50), "p99": pct(99), "max": round(float(per_step.max()), 4), "min": round(float(per_step.min()), 4)},
@@ -491,7 +497,9 @@ def run_sustained(args, torch, dist, step, fence, stream, local_rank, n_steps, B
         "last_vs_first_second": round(last / first, 4) if first else None,
         "sclk_mhz": {"min": min(sclk), "median": round(float(np.median(sclk)), 1), "first_second": sclk[0], "last_second": sclk[-1]} if sclk else None,
         "power_w": {"median": round(float(np.median(power)), 1), "max": max(power), "first_second": power[0], "last_second": power[-1]} if power else None,
+        "frames_per_joule": round(B * n_steps / wall_all / float(np.median(power)), 1) if power else None,     # rank 0's GPU: its frames / its socket energy
         "temperature_c": {lb: {"first_second": v[0], "last_second": v[-1], "max": max(v)} for lb, v in temps.items() if v} or None,
+        "first_3s_mean_ms_per_step_by_100ms": early,
         "per_second": [{"t": k, "frames_per_s": rate[k], **trace[k]} for k in range(0, full, stride)],
         "note": "same step loop as the timed region, run back to back (hipEvent per step, read a chunk behind so the queue never drains); per-second rows: "
                 "steps completed in that second x frames, medians of the 100 ms sysfs samples of rank 0's GPU",
@@ -817,9 +825,11 @@ def main():
                           "slowest_step_index": int(np.argmax(per_step)),
                           "note": "hipEvent time between consecutive steps' last kernels on rank 0's stream"}
         out["gpu_clock"] = clk.summary()
-        pw = (out["gpu_clock"] or {}).get("power_w_median")
-        if pw:   # the LDPC kernel runs power-limited: energy per frame is the other side of frames/s (rank 0's GPU, socket power from hwmon)
-            out["gpu_clock"]["frames_per_joule"] = round((total / max(world, 1)) * args.steps / elapsed / pw, 1)
+        if (out["gpu_clock"] or {}).get("power_w_median"):
+            # hwmon's socket power is a moving average with a time constant of a fraction of a second: over a timed region of
+            # K x 4 ms that follows 0.1 s of warm-up from idle it still reads hundreds of watts low (round 5 quoted 889 W from here;
+            # a 60 s run of the same loop reads 1 380 W, --sustain-seconds).  Energy per frame is therefore reported there only.
+            out["gpu_clock"]["power_note"] = "moving average, lags a burst this short: read sustained.power_w (--sustain-seconds) for the power this loop draws"
         out["prewarm_steps"] = args.prewarm        # untimed, before the W warm-up steps (clock ramp after idle; see --prewarm)
         out["config"]["decoded_messages_per_frame"] = round(float(nres.cpu().numpy().mean()), 2)
         # slots the path wrote (messages whose first token starts with "CQ", rtlsdr_ft8d.c:1509-1519); the other messages are

@@ -550,14 +550,20 @@ def test_failed_buffer_growth_leaves_the_context_as_it_was():
         before = (spots.cpu().numpy().tobytes(), nres.cpu().numpy().tobytes())
         need_status = F * 1024 * 48                              # 1.6 GB: the second buffer of the growth to cap 1024 (the first is 268 MB)
         free, _ = torch.cuda.mem_get_info()
-        filler, left = [], free - (need_status - (256 << 20))    # leave less than the second buffer needs, more than the first
-        while left > (64 << 20):
-            sz = min(left, 8 << 30)
+        # leave less than the second buffer needs and more than the first: fill in pieces, halving the piece size whenever the
+        # allocator refuses one (the driver's own granularity and fragmentation decide what still fits near the end)
+        filler, piece, target = [], 8 << 30, need_status - (256 << 20)
+        while piece >= (32 << 20):
+            free_now, _ = torch.cuda.mem_get_info()
+            if free_now <= target:
+                break
+            sz = min(piece, free_now - target)
+            if sz < (32 << 20):
+                break
             try:
                 filler.append(torch.empty(sz, dtype=torch.uint8, device="cuda"))
-                left -= sz
             except torch.OutOfMemoryError:
-                break
+                piece //= 2
         free_now, _ = torch.cuda.mem_get_info()
         assert free_now < need_status, (free_now, need_status)
         with pytest.raises(ft8.Ft8GpuError, match="out of device memory"):

@@ -1,10 +1,10 @@
 #!/bin/bash
 # one GPU-box session: [tests] [bench] [prof] [pmc] -- stages picked by $STAGES (default: all)
-#   tests  parity tests + smoke            bench  bench.py (configs 2, 4, 1, 3) + the RCCL one-rank legs
+#   tests  parity tests + smoke            bench  bench.py (configs 2, 4, 1, 3) + the RCCL one-rank legs (+ SUSTAIN=60: a sustained run)
 #   prof   rocprofv3 kernel trace + stats  pmc    the four PMC passes (SQ / SQ+GRBM / FETCH_SIZE / WRITE_SIZE) for configs 2, 4 and 1
 # Summaries land in gpurun_out/profiles_$TAG/; copy them to profiles/ to have them judged.  A profiler pass that
 # fails (non-zero exit, or no CSV where one is expected) aborts its stage and leaves profiles/ untouched.
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 STAGES=${STAGES:-"tests bench prof pmc"}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
@@ -66,8 +66,10 @@ if has bench; then
   python bench.py --config 3 --steps 5 --warmup 2 > gpurun_out/bench_c3.log 2>&1; tail -1 gpurun_out/bench_c3.log > $OUT/${TAG}_bench_config3_one_gpu.json; cut -c1-300 $OUT/${TAG}_bench_config3_one_gpu.json
   python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-legs --force-dist > gpurun_out/bench_dist1.log 2>&1; tail -1 gpurun_out/bench_dist1.log > $OUT/${TAG}_bench_rccl_one_rank.json; cut -c1-200 $OUT/${TAG}_bench_rccl_one_rank.json
   python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-legs --force-dist --ctx-last > gpurun_out/bench_dist1_last.log 2>&1; tail -1 gpurun_out/bench_dist1_last.log > $OUT/${TAG}_bench_rccl_one_rank_ctx_last.json; cut -c1-200 $OUT/${TAG}_bench_rccl_one_rank_ctx_last.json
+  python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-legs --force-dist --no-exchange > gpurun_out/bench_dist1_noex.log 2>&1; tail -1 gpurun_out/bench_dist1_noex.log > $OUT/${TAG}_bench_rccl_one_rank_no_exchange.json; cut -c1-200 $OUT/${TAG}_bench_rccl_one_rank_no_exchange.json
   python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-legs > gpurun_out/bench_plain2.log 2>&1; tail -1 gpurun_out/bench_plain2.log > $OUT/${TAG}_bench_no_dist_same_session.json; cut -c1-200 $OUT/${TAG}_bench_no_dist_same_session.json
   python bench.py --steps 20 --warmup 5 --traffic mixed --no-host-legs > gpurun_out/bench_mixed.log 2>&1; tail -1 gpurun_out/bench_mixed.log > $OUT/${TAG}_bench_mixed.json; cut -c1-200 $OUT/${TAG}_bench_mixed.json
-  [ -f tools/ab/libft8gpu_r04.so ] && { python tools/ab_libs.py --libs tools/ab/libft8gpu_r04.so rtlsdr_ft8d_amd/libft8gpu.so --rounds 3 > gpurun_out/ab_r04.log 2>&1; tail -1 gpurun_out/ab_r04.log > $OUT/${TAG}_ab_r04_vs_r05.json; cut -c1-300 $OUT/${TAG}_ab_r04_vs_r05.json; }
+  [ -n "${SUSTAIN:-}" ] && { python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-legs --sustain-seconds $SUSTAIN > gpurun_out/bench_sustain.log 2>&1; tail -1 gpurun_out/bench_sustain.log > $OUT/${TAG}_bench_sustained_${SUSTAIN}s.json; cut -c1-200 $OUT/${TAG}_bench_sustained_${SUSTAIN}s.json; }
+  [ -f tools/ab/libft8gpu_r05.so ] && { python tools/ab_libs.py --libs tools/ab/libft8gpu_r05.so rtlsdr_ft8d_amd/libft8gpu.so --rounds 3 > gpurun_out/ab_r05.log 2>&1; tail -1 gpurun_out/ab_r05.log > $OUT/${TAG}_ab_r05_vs_${TAG}.json; cut -c1-300 $OUT/${TAG}_ab_r05_vs_${TAG}.json; }
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-host-legs > gpurun_out/bench_torchrun1.log 2>&1; tail -1 gpurun_out/bench_torchrun1.log | cut -c1-200
 fi
