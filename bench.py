@@ -86,6 +86,12 @@ def parse_args(argv=None):
                     help="untimed steps run before the W warm-up steps: after any idle period the GPU needs about 30 ms of load to "
                          "reach its sustained clock (per-step times from cold: 5.65, 4.82, 4.67, 4.54, 4.48, 4.38, 4.25, 4.25 ... ms, "
                          "tools/perstep_probe.py), which short --warmup values would put inside the timed region; reported in the line")
+    ap.add_argument("--prewarm-seconds", type=float, default=1.0,
+                    help="after the --prewarm steps keep running untimed steps for about this long before the W warm-up steps (the step count is "
+                         "fixed from a short calibration, the same on every rank): on some boxes of the pool the shader clock is still settling "
+                         "0.1 s after idle -- a 60 s run of the same loop was 2.2 %% faster than the 80 ms timed region that preceded it on one box, "
+                         "equal on another (profiles/r06_bench_sustained_60s*.json) -- so the timed region starts from the state a replay job "
+                         "runs in; the steps actually run are reported as prewarm_steps")
     ap.add_argument("--no-clock-sampler", action="store_true", help="do not poll the GPU's sysfs clock / power files during the timed region")
     ap.add_argument("--ctx-last", action="store_true",
                     help="create the decoder context AFTER the process group and a handful of framework streams (round 3 lost 0.27 ms per step "
@@ -763,7 +769,27 @@ def main():
         # the clock / power sampler starts before the warm-up so that its thread start-up does not land in the first timed step
         with ClockSampler(local_rank, not args.no_clock_sampler) as clk:
             enter("warmup_with_exchange" if exchange else "warmup")
-            for _ in range(args.prewarm + args.warmup):
+            n_pre = args.prewarm
+            for _ in range(args.prewarm):
+                step()
+            if args.prewarm_seconds > 0:
+                fence()
+                t_cal = time.perf_counter()
+                for _ in range(8):
+                    step()
+                fence()
+                extra = int(min(5000, np.ceil(args.prewarm_seconds / max((time.perf_counter() - t_cal) / 8, 1e-4))))
+                if use_dist:                     # the exchange is a collective: every rank runs the same number of steps
+                    nmax = torch.tensor([extra], dtype=torch.int64, device=dev)
+                    dist.all_reduce(nmax, op=dist.ReduceOp.MAX)
+                    extra = int(nmax.item())
+                for i in range(extra):
+                    step()
+                    if (i & 127) == 127:
+                        exch.wait_all()
+                        torch.cuda.synchronize()
+                n_pre += 8 + extra
+            for _ in range(args.warmup):
                 step()
             fence()
             enter("timed_steps", args.dist_timeout + 60.0)
@@ -830,7 +856,8 @@ def main():
             # K x 4 ms that follows 0.1 s of warm-up from idle it still reads hundreds of watts low (round 5 quoted 889 W from here;
             # a 60 s run of the same loop reads 1 380 W, --sustain-seconds).  Energy per frame is therefore reported there only.
             out["gpu_clock"]["power_note"] = "moving average, lags a burst this short: read sustained.power_w (--sustain-seconds) for the power this loop draws"
-        out["prewarm_steps"] = args.prewarm        # untimed, before the W warm-up steps (clock ramp after idle; see --prewarm)
+        out["prewarm_steps"] = n_pre               # untimed, before the W warm-up steps (clock settling after idle; see --prewarm-seconds)
+        out["prewarm_seconds"] = args.prewarm_seconds
         out["config"]["decoded_messages_per_frame"] = round(float(nres.cpu().numpy().mean()), 2)
         # slots the path wrote (messages whose first token starts with "CQ", rtlsdr_ft8d.c:1509-1519); the other messages are
         # counted in n_results and leave their slot as the caller's array had it (zeros here)

@@ -16,7 +16,7 @@ if has tests; then
   grep -E "passed|failed|rc=" gpurun_out/pytest_gpu.log | tail -3
   python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; tail -1 gpurun_out/smoke.log
 fi
-CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-legs"
+CMD="python3 bench.py --steps 3 --warmup 1 --prewarm-seconds 0 --no-cpu-baseline --no-host-legs"
 # one rocprofv3 counter pass; fails unless the profiler exits 0 AND wrote its counter CSV
 pmc_pass() {   # $1 = dir, $2 = name, $3 = counters (quoted), $4.. = the program
   local d=$1 n=$2 c=$3; shift 3
