@@ -167,3 +167,34 @@ def test_pin_recipe_names_the_revision_to_check_out_from_the_clones_own_history(
     git("checkout", "-q", shas[2])
     rc, out = _pin(up)
     assert rc == 0
+
+
+def test_pin_recipe_falls_back_to_the_public_interface_when_internal_names_differ(tmp_path):
+    """the three stages behind the public calls are reached through upstream's file-local functions; a revision of the right era
+    that spells one differently gets the public-interface comparison plus the -D overrides to name its equivalents -- not a
+    compiler error (declaration-only fake trees; PIN_PLAN_ONLY stops before anything is compiled)"""
+    full, bare = str(tmp_path / "full"), str(tmp_path / "bare")
+    for d in (full, bare):
+        _fake_tree(d, _ERA_H)
+        with open(os.path.join(d, "ft8", "ldpc.h"), "w") as f:
+            f.write("void bp_decode(float codeword[], int max_iters, uint8_t plain[], int* ok);\n")
+    with open(os.path.join(full, "ft8", "decode.c"), "w") as f:
+        f.write("static int ft8_sync_score(const waterfall_t* wf, const candidate_t* c);\n"
+                "static void ft8_extract_likelihood(const waterfall_t* wf, const candidate_t* c, float* log174);\n"
+                "static void ftx_normalize_logl(float* log174);\n")
+    with open(os.path.join(bare, "ft8", "decode.c"), "w") as f:
+        f.write("static int get_sync_score(const waterfall_t* wf, const candidate_t* c);\n"
+                "static void ft8_extract_likelihood(const waterfall_t* wf, const candidate_t* c, float* log174);\n")
+
+    def plan(up, **env):
+        p = subprocess.run(["bash", os.path.join(ROOT, "tools", "pin_ft8_lib.sh"), up], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, PIN_PLAN_ONLY="1", **env))
+        return p.returncode, p.stdout + p.stderr
+
+    rc, out = plan(full)
+    assert rc == 0 and "comparison depth: public interface + internals" in out and "NOTE" not in out
+    rc, out = plan(bare)
+    assert rc == 0 and "comparison depth: public interface only" in out
+    assert "does not define: ft8_sync_score ftx_normalize_logl" in out and "-DPIN_UPSTREAM_SYNC_SCORE=<fn>" in out
+    rc, out = plan(bare, PIN_EXTRA_CFLAGS="-DPIN_UPSTREAM_SYNC_SCORE=get_sync_score -DPIN_UPSTREAM_NORMALIZE=normalize")
+    assert rc == 0 and "comparison depth: public interface + internals" in out

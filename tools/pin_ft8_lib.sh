@@ -79,22 +79,47 @@ if [ "$era" != ok ]; then
 fi
 echo "API era: ft8_find_sync / ft8_decode with waterfall_t.protocol -- the interface rtlsdr_ft8d.c:1439-1494 calls"
 [ -n "${PIN_CHECK_ERA_ONLY:-}" ] && exit 0
+# ---- how deep can the comparison go with THIS checkout? -----------------------------------------------------------------
+# Beyond the public calls the harness compares three stages behind them (every sync score, the normalised LLR bit patterns, BP
+# convergence) through upstream's file-local functions, which upstream_internals.c reaches by including ft8/decode.c.  Their
+# names are those of the era's revisions as far as the call sites tell; a revision that spells one differently still gets the
+# public-interface comparison (ordered candidate lists at three caps, every ft8_decode outcome incl. text / CRCs / hash,
+# pack77, ft8_encode) instead of a compiler error, and the note says which -DPIN_UPSTREAM_*=<name> brings the rest back.
+INT=-DPIN_INTERNALS
+missing=""
+for n in ft8_sync_score ft8_extract_likelihood ftx_normalize_logl; do
+    has "\\b$n[[:space:]]*\\(" "$UP/ft8/decode.c" || missing="$missing $n"
+done
+has '\bbp_decode[[:space:]]*\(' "$UP/ft8/ldpc.h" || missing="$missing bp_decode(ft8/ldpc.h)"
+if [ -n "$missing" ] && [ -z "${PIN_EXTRA_CFLAGS:-}" ]; then
+    INT=""
+    echo "NOTE: this revision does not define:$missing"
+    echo "      -> comparing the PUBLIC interface only.  To include sync scores / LLRs / BP convergence, name its equivalents:"
+    echo "         PIN_EXTRA_CFLAGS='-DPIN_UPSTREAM_SYNC_SCORE=<fn> -DPIN_UPSTREAM_EXTRACT_LLR=<fn> -DPIN_UPSTREAM_NORMALIZE=<fn>' $0 $UP"
+fi
+echo "comparison depth: $([ -n "$INT" ] && echo 'public interface + internals (sync scores, LLR bits, BP convergence)' || echo 'public interface only')"
+[ -n "${PIN_PLAN_ONLY:-}" ] && exit 0
 make -s -C "$ROOT/oracle"
 python3 "$P/make_inputs.py" "$W" ${PIN_LIGHT:+--light}
-CFLAGS="-O2 -std=gnu17 -ffp-contract=off -fno-fast-math"      # one IEEE operation per float operation on both sides
-# (a) upstream: its own sources; decode.c comes in through upstream_internals.c (which wraps its file-local functions)
+CFLAGS="-O2 -std=gnu17 -ffp-contract=off -fno-fast-math ${PIN_EXTRA_CFLAGS:-}"      # one IEEE operation per float operation on both sides
+# (a) upstream: its own sources; with internals decode.c comes in through upstream_internals.c (which wraps its file-local functions)
 UPSRC=""
 for f in constants crc ldpc unpack text pack encode; do [ -f "$UP/ft8/$f.c" ] && UPSRC="$UPSRC $UP/ft8/$f.c"; done
-gcc $CFLAGS -DPIN_INTERNALS -I"$UP" -I"$P" "$P/pin_harness.c" "$P/upstream_internals.c" $UPSRC -lm -o "$W/pin_upstream"
-# (b) the oracle under the same names
-gcc $CFLAGS -DPIN_INTERNALS -I"$ROOT/include/ft8_lib" -I"$ROOT/oracle" -I"$P" "$P/pin_harness.c" "$P/oracle_as_ft8_lib.c" \
+if [ -n "$INT" ] && ! gcc $CFLAGS $INT -I"$UP" -I"$P" "$P/pin_harness.c" "$P/upstream_internals.c" $UPSRC -lm -o "$W/pin_upstream" 2> "$W/internals_build.log"; then
+    head -20 "$W/internals_build.log"
+    echo "NOTE: the internals backend does not compile against this revision (log: $W/internals_build.log) -> public interface only"
+    INT=""
+fi
+[ -n "$INT" ] || gcc $CFLAGS -I"$UP" -I"$P" "$P/pin_harness.c" "$UP/ft8/decode.c" $UPSRC -lm -o "$W/pin_upstream"
+# (b) the oracle under the same names, at the same depth
+gcc $CFLAGS $INT -I"$ROOT/include/ft8_lib" -I"$ROOT/oracle" -I"$P" "$P/pin_harness.c" "$P/oracle_as_ft8_lib.c" \
     -L"$ROOT/oracle" -lft8oracle -Wl,-rpath,"$ROOT/oracle" -lm -o "$W/pin_oracle"
 "$W/pin_upstream" "$W/waterfalls.bin" "$W/messages.txt" > "$W/upstream.txt"
 "$W/pin_oracle" "$W/waterfalls.bin" "$W/messages.txt" > "$W/oracle.txt"
 echo "upstream revision: $(git -C "$UP" rev-parse HEAD 2>/dev/null || echo unknown)"
 echo "records: $(wc -l < "$W/oracle.txt") (oracle), $(wc -l < "$W/upstream.txt") (upstream); dumps in $W"
 if diff -u "$W/upstream.txt" "$W/oracle.txt" > "$W/pin.diff"; then
-    echo "PINNED: the oracle and upstream ft8_lib agree on every record"
+    echo "PINNED: the oracle and upstream ft8_lib agree on every record ($([ -n "$INT" ] && echo 'public interface + internals' || echo 'PUBLIC INTERFACE ONLY: see the note above'))"
 else
     head -60 "$W/pin.diff"
     echo "DIFFERENT: $(grep -c '^[-+][^-+]' "$W/pin.diff") lines differ (full diff: $W/pin.diff)"
