@@ -113,8 +113,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-exchange", action="store_true",
                     help="multi-rank control leg: the ranks decode their shards with NO collective in the step (barrier and timing reduction only), so "
                          "that a scaling curve separates decode scaling from the cost of the spot gather")
-    ap.add_argument("--test-hang", default=None, metavar="RANK:PHASE",
-                    help="test hook: that rank sleeps forever when it enters that phase (what a hung RCCL init looks like to the watchdog)")
+    ap.add_argument("--test-hang", default=None, metavar="RANK:PHASE[:SECONDS]",
+                    help="test hook: that rank sleeps forever when it enters that phase (what a hung RCCL init looks like to the watchdog); "
+                         "SECONDS = the watchdog limit of that phase only")
     ap.add_argument("--test-fail-exchange", default=None, metavar="RANK:STEP",
                     help="test hook: that rank's exchange raises at that step (what a failing collective looks like to the error path)")
     ap.add_argument("--traffic", choices=("cq", "mixed"), default="cq",
@@ -235,6 +236,15 @@ def _rank_step(spec):
         return None
     r, x = spec.split(":", 1)
     return int(r), x
+
+
+def _hang_spec(spec):
+    """--test-hang 'RANK:PHASE[:SECONDS]' -> ((RANK, PHASE), seconds or None): the optional third field is the watchdog limit of
+    THAT phase only, so that a test can keep a generous --dist-timeout for the real phases (a cold RCCL load takes a while)"""
+    if not spec:
+        return None, None
+    f = spec.split(":")
+    return (int(f[0]), f[1]), (float(f[2]) if len(f) > 2 else None)
 
 
 def store_publish(store, key, value):
@@ -531,12 +541,13 @@ def main():
     use_dist = world > 1 or args.force_dist
     # the watchdog child exists before this process imports torch or touches the GPU (multi-rank / forced-dist runs only)
     wd = RankWatchdog(rank, world, use_dist, args.dist_timeout)
-    hang = _rank_step(args.test_hang)
+    hang, hang_limit = _hang_spec(args.test_hang)
 
     def enter(phase, timeout=None):
-        wd.phase(phase, timeout)
         if hang and hang == (rank, phase):
+            wd.phase(phase, hang_limit or timeout)
             time.sleep(10 ** 7)                  # test hook: what a rank stuck inside a library call looks like from outside
+        wd.phase(phase, timeout)
 
     enter("import_torch", max(args.dist_timeout, 600.0))        # the first import on a fresh box pages the image in: minutes
     import datetime
