@@ -24,6 +24,10 @@ def main():
     ap.add_argument("--vary-min-score", action="store_true",
                     help="draw K_MIN_SCORE per batch from 10, 10, 5, 0, -3, 20, 30 (the reference fixes 10, rtlsdr_ft8d.h:43; the run-time form must "
                          "follow the same rules at any threshold: at 0 and below every position of the scan survives the gate)")
+    ap.add_argument("--vary-frames", action="store_true",
+                    help="draw the number of frames of each batch log-uniformly from 1 ... --frames (and once in eight exactly at a threshold of the "
+                         "pipeline: 511, 512, 513, 1024, 1025, 2048, 2049): the plain and the two-part pipeline, the part split, the heap kernel forms "
+                         "chosen by launch size and the 1024-frame chunks of the stage comparison all depend on it")
     ap.add_argument("--vary-iters", action="store_true",
                     help="draw K_LDPC_ITERS per batch from 20, 20, 1, 5, 13, 50 on both sides (the reference fixes 20, rtlsdr_ft8d.h:45, and passes it "
                          "at rtlsdr_ft8d.c:1476; the kernel's iteration loop, its skipped dead last update and the iteration field of the status "
@@ -45,12 +49,13 @@ def main():
     from bench import usable_cores
     cores = usable_cores()
     build_id = ft8.check_build_id()               # a stale or foreign library is refused before anything is measured
-    B = args.frames
+    B = BMAX = args.frames
+    sizes = []
     mixed = args.traffic == "mixed"
     _, tones = workload.message_pool(traffic=args.traffic)
     fill = 0xA5 if mixed else 0
     stale_rec = np.full(28, fill, np.uint8).tobytes()
-    start = np.full((B, 1400), fill, np.uint8).view(O.RESULT_DTYPE).reshape(B, 50) if mixed else None
+    start_all = np.full((B, 1400), fill, np.uint8).view(O.RESULT_DTYPE).reshape(B, 50) if mixed else None
     rng = np.random.default_rng(args.seed)
     dec = ft8.Decoder(device=0, max_frames=B)
     iq = torch.empty((B, 2, ft8.NSAMPLES), dtype=torch.float32, device="cuda")
@@ -67,9 +72,13 @@ def main():
         cap = int(rng.choice([120, 120, 120, 60, 240, 480]))
         min_score = int(rng.choice([10, 10, 5, 0, -3, 20, 30])) if args.vary_min_score else 10
         iters = int(rng.choice([20, 20, 1, 5, 13, 50])) if args.vary_iters else 20
+        if args.vary_frames:
+            B = int(rng.choice([511, 512, 513, 1024, 1025, 2048, 2049])) if rng.integers(0, 8) == 0 else int(round(float(np.exp(rng.uniform(0.0, np.log(BMAX))))))
+            B = max(1, min(B, BMAX))
+            sizes.append(B)
         iters_hist[iters] = iters_hist.get(iters, 0) + B
         dec.set_params(min_score=min_score, max_candidates=cap, ldpc_iters=iters)
-        sig, _ = workload.frame_signals(1_000_000 + (args.seed - 123) * 10_000_000 + b * B, B, nsig, tones, snr_range=(lo_snr, hi_snr),
+        sig, _ = workload.frame_signals(1_000_000 + (args.seed - 123) * 10_000_000 + b * BMAX, B, nsig, tones, snr_range=(lo_snr, hi_snr),
                                         dup_fraction=workload.MIXED_DUP_FRACTION if mixed else 0.0,
                                         **(dict(f_range=(-20.0, 1620.0), dt_range=(-1.5, 3.0)) if args.edges else {}))
         dec.synth_frames(sig, B, nsig, 1.0, 777 + b + (args.seed - 123) * 100_003, iq)
@@ -77,9 +86,10 @@ def main():
         torch.cuda.synchronize()                     # the fill runs on torch's stream, the decoder on its own
         dec.decode_batch_dev(iq, B, spots, nres)
         dec.synchronize()
-        g = spots.cpu().numpy().view(ft8.RESULT_DTYPE).reshape(B, 50)
-        gn = nres.cpu().numpy()
-        rdec, rn = O.subsystem_batch(iq.cpu().numpy(), O.default_params(min_score, cap, iters), cores, decodes=start)
+        g = spots[:B].cpu().numpy().view(ft8.RESULT_DTYPE).reshape(B, 50)
+        gn = nres[:B].cpu().numpy()
+        start = start_all[:B] if start_all is not None else None
+        rdec, rn = O.subsystem_batch(iq[:B].cpu().numpy(), O.default_params(min_score, cap, iters), cores, decodes=start)
         mism = [k for k in range(B) if gn[k] != rn[k] or g[k].tobytes() != rdec[k].tobytes()]
         if args.records:
             before = stage_check.differing(stages)
@@ -88,11 +98,11 @@ def main():
                 print(f"batch {b}: stage boundaries differ: {stages} first {first_bad}", flush=True)
         w = int(sum(1 for k in range(B) for j in range(min(int(gn[k]), 50)) if g[k, j].tobytes() != stale_rec)) if mixed else int(np.minimum(gn, 50).sum())
         bad += len(mism); total += B; msgs += int(gn.sum()); written += w
-        print(f"batch {b}: nsig {nsig} snr [{lo_snr:.0f},{hi_snr:.0f}] cap {cap} min_score {min_score} iters {iters}: {int(gn.sum())} messages, {w} CQ spots, mismatching frames {len(mism)}", flush=True)
+        print(f"batch {b}: {B} frames, nsig {nsig} snr [{lo_snr:.0f},{hi_snr:.0f}] cap {cap} min_score {min_score} iters {iters}: {int(gn.sum())} messages, {w} CQ spots, mismatching frames {len(mism)}", flush=True)
     print(json.dumps({"frames": total, "messages": msgs, "cq_spots_written": written, "mismatching_frames": bad, "seconds": round(time.time() - t0, 1), "seed": args.seed,
                       "batches": args.batches, "traffic": args.traffic, "edges": bool(args.edges), "vary_min_score": bool(args.vary_min_score), "initial_record_byte": fill, "messages_per_frame": round(msgs / max(total, 1), 3),
                       "cq_spots_per_frame": round(written / max(total, 1), 3), "build_id": build_id,
-                      "vary_iters": bool(args.vary_iters), "frames_by_ldpc_iters": {str(k): v for k, v in sorted(iters_hist.items())},
+                      "vary_iters": bool(args.vary_iters), "vary_frames": bool(args.vary_frames), **({"batch_sizes_min_median_max": [int(min(sizes)), int(np.median(sizes)), int(max(sizes))], "batches_below_512_frames": int(sum(x < 512 for x in sizes))} if sizes else {}), "frames_by_ldpc_iters": {str(k): v for k, v in sorted(iters_hist.items())},
                       **({"stages": stages, "stage_differences_total": stage_check.differing(stages), "first_differences": first_bad} if args.records else {})}))
     return 1 if bad or (args.records and stage_check.differing(stages)) else 0
 
