@@ -22,10 +22,46 @@ def new_counters():
                 pipeline_form_ldpc_errors_not_0_or_83=0)
 
 
+def compare_with_oracle(O, iq_host, h_mag, h_cands, h_counts, g_stage, g_pipe, cap, min_score, iters, cores, c, first_bad=None, f0=0):
+    """the comparison itself, numpy only (a CPU test feeds it doctored arrays: a checker must be seen to fail).
+    iq_host [m][2][48000] f32; h_mag [m][94208] u8, h_cands [m][cap] CAND_DTYPE, h_counts [m] i32: the device's waterfall and
+    candidate lists; g_stage / g_pipe [m][cap][48] u8: the status records of the two kernel forms."""
+    m = len(h_counts)
+    ref_mag = O.waterfall_batch(iq_host, False, cores)
+    wdiff = h_mag != ref_mag
+    c["waterfall_cells"] += h_mag.size
+    c["waterfall_cells_differing"] += int(wdiff.sum())
+    c["waterfall_frames_differing"] += int(wdiff.any(axis=1).sum())
+    ref_cands, ref_counts = O.find_sync_batch(ref_mag, cap, min_score, cores)
+    lbad = (h_counts != ref_counts) | (h_cands.view(np.uint64) != ref_cands.view(np.uint64)).any(axis=1).reshape(m)
+    c["candidate_lists_differing"] += int(lbad.sum())
+    want = O.decode_candidates_batch(h_mag, h_cands, h_counts, iters, cores)
+    live = np.arange(cap)[None, :] < h_counts[:, None]
+    sbad = (g_stage != want).any(axis=2)             # slots at and beyond the count included: nothing may be written there
+    # pipeline form: the error count is 0 or 83 and is zero exactly where the oracle's is; all other bytes equal
+    pe = g_pipe[:, :, 0:2].copy().view(np.int16)[..., 0]
+    we = want[:, :, 0:2].copy().view(np.int16)[..., 0]
+    c["pipeline_form_ldpc_errors_not_0_or_83"] += int((live & (pe != 0) & (pe != FT8_LDPC_M)).sum())
+    pbad = ((g_pipe[:, :, 2:] != want[:, :, 2:]).any(axis=2) | ((pe == 0) != (we == 0)))
+    c["frames"] += m
+    c["candidate_records"] += int(h_counts.sum())
+    c["candidate_records_decoded_ok"] += int((want[:, :, 9] == 1)[live].sum())
+    c["records_differing_stage_form"] += int(sbad.sum())
+    c["records_differing_pipeline_form"] += int(pbad.sum())
+    if first_bad is not None and len(first_bad) < 8:
+        for name, arr in (("waterfall", wdiff.any(axis=1)), ("candidate_list", lbad)):
+            for f in np.flatnonzero(arr)[:2]:
+                first_bad.append((name, f0 + int(f), -1))
+        for name, arr in (("record_stage_form", sbad), ("record_pipeline_form", pbad)):
+            for f, k in np.argwhere(arr)[:2]:
+                first_bad.append((name, f0 + int(f), int(k)))
+    return c
+
+
 def stage_boundaries_vs_oracle(ft8, O, dec, iq, nframes, cap, min_score, iters, cores, counters=None, chunk=1024, first_bad=None):
     """iq: [nframes][2][48000] float32 on the device; dec's parameters must already be (min_score, cap, iters) and cap must not
-    exceed what dec was created / set for.  Adds to `counters` (new_counters()) and returns it; `first_bad` (a list) receives
-    up to 8 (stage, frame, candidate) tuples."""
+    exceed what dec was created / set for (the context's debug flags are left at 0).  Adds to `counters` (new_counters()) and
+    returns it; `first_bad` (a list) receives up to 8 (stage, frame, candidate) tuples."""
     import torch
     c = counters if counters is not None else new_counters()
     for f0 in range(0, nframes, chunk):
@@ -51,35 +87,7 @@ def stage_boundaries_vs_oracle(ft8, O, dec, iq, nframes, cap, min_score, iters, 
         h_cands = cands.cpu().numpy().view(O.CAND_DTYPE).reshape(m, cap)
         g_stage, g_pipe = st_stage.cpu().numpy(), st_pipe.cpu().numpy()
         del mag, cands, counts, st_stage, st_pipe
-
-        ref_mag = O.waterfall_batch(part.cpu().numpy(), False, cores)
-        wdiff = h_mag != ref_mag
-        c["waterfall_cells"] += h_mag.size
-        c["waterfall_cells_differing"] += int(wdiff.sum())
-        c["waterfall_frames_differing"] += int(wdiff.any(axis=1).sum())
-        ref_cands, ref_counts = O.find_sync_batch(ref_mag, cap, min_score, cores)
-        lbad = (h_counts != ref_counts) | (h_cands.view(np.uint64) != ref_cands.view(np.uint64)).any(axis=1).reshape(m)
-        c["candidate_lists_differing"] += int(lbad.sum())
-        want = O.decode_candidates_batch(h_mag, h_cands, h_counts, iters, cores)
-        live = np.arange(cap)[None, :] < h_counts[:, None]
-        sbad = (g_stage != want).any(axis=2)             # slots at and beyond the count included: nothing may be written there
-        # pipeline form: the error count is 0 or 83 and is zero exactly where the oracle's is; all other bytes equal
-        pe = g_pipe[:, :, 0:2].copy().view(np.int16)[..., 0]
-        we = want[:, :, 0:2].copy().view(np.int16)[..., 0]
-        c["pipeline_form_ldpc_errors_not_0_or_83"] += int((live & (pe != 0) & (pe != FT8_LDPC_M)).sum())
-        pbad = ((g_pipe[:, :, 2:] != want[:, :, 2:]).any(axis=2) | ((pe == 0) != (we == 0)))
-        c["frames"] += m
-        c["candidate_records"] += int(h_counts.sum())
-        c["candidate_records_decoded_ok"] += int((want[:, :, 9] == 1)[live].sum())
-        c["records_differing_stage_form"] += int(sbad.sum())
-        c["records_differing_pipeline_form"] += int(pbad.sum())
-        if first_bad is not None and len(first_bad) < 8:
-            for name, arr in (("waterfall", wdiff.any(axis=1)), ("candidate_list", lbad)):
-                for f in np.flatnonzero(arr)[:2]:
-                    first_bad.append((name, f0 + int(f), -1))
-            for name, arr in (("record_stage_form", sbad), ("record_pipeline_form", pbad)):
-                for f, k in np.argwhere(arr)[:2]:
-                    first_bad.append((name, f0 + int(f), int(k)))
+        compare_with_oracle(O, part.cpu().numpy(), h_mag, h_cands, h_counts, g_stage, g_pipe, cap, min_score, iters, cores, c, first_bad, f0)
     return c
 
 

@@ -556,3 +556,59 @@ def test_the_one_ulp_square_root_cases_are_explained_on_the_cpu(oracle):
         assert outputs(raw * np.nextafter(norm, F32(0))) == old, k  # (c)
         differing += sum(a != b for a, b in zip(old, ref))
     assert differing >= len(cases)                                  # the fixture holds real differences
+
+
+def test_stage_checker_fails_when_it_should(oracle):
+    """tests/stage_check.compare_with_oracle is what holds the GPU to the oracle at every stage boundary (the driver-run config
+    tests, tools/soak_parity.py).  A checker has to be SEEN to fail: fed the oracle's own outputs it is clean; one waterfall
+    cell, one candidate, one byte of a stage-form record, one text character of a pipeline-form record, a pipeline-form error
+    count that is neither 0 nor 83, a record written beyond the count -- each is counted, in the right counter."""
+    import stage_check
+    import synth_util
+    O = oracle
+    enc = synth_util.oracle_encode_fn(O)
+    iq = np.stack([synth_util.make_frame(900 + k, 6, enc, snr_range=(-14.0, 0.0))[0] for k in range(4)])
+    cap, min_score, iters = 60, 10, 20
+    mag = O.waterfall_batch(iq, False, 2)
+    cands, counts = O.find_sync_batch(mag, cap, min_score, 2)
+    st = O.decode_candidates_batch(mag, cands, counts, iters, 2)
+    pipe = st.copy()
+    e = pipe[:, :, 0:2].view(np.int16)
+    e[e != 0] = 83                                               # what the pipeline form of the kernel reports
+
+    def run(mag_=mag, cands_=cands, counts_=counts, st_=st, pipe_=pipe):
+        c, fb = stage_check.new_counters(), []
+        stage_check.compare_with_oracle(O, iq, mag_, cands_, counts_, st_, pipe_, cap, min_score, iters, 2, c, fb)
+        return c, fb
+
+    c, fb = run()
+    assert stage_check.differing(c) == 0 and not fb and c["frames"] == 4 and c["candidate_records"] == int(counts.sum()) > 40
+    assert c["candidate_records_decoded_ok"] >= 8
+    ok = np.argwhere(st[:, :, 9] == 1)
+    f, k = map(int, ok[0])
+    m2 = mag.copy(); m2[2, 5000] ^= 1                             # (the records are then compared for THIS waterfall: only the cell counts)
+    c, fb = run(mag_=m2)
+    assert c["waterfall_cells_differing"] == 1 and c["waterfall_frames_differing"] == 1 and ("waterfall", 2, -1) in fb
+    c2 = cands.copy(); c2[1, 0]["freq_offset"] += 1
+    c, fb = run(cands_=c2)
+    assert c["candidate_lists_differing"] == 1 and ("candidate_list", 1, -1) in fb
+    s2 = st.copy(); s2[f, k, 12] ^= 0x10                          # a packed bit of a decoded message
+    c, fb = run(st_=s2)
+    assert c["records_differing_stage_form"] == 1 and c["records_differing_pipeline_form"] == 0 and ("record_stage_form", f, k) in fb
+    p2 = pipe.copy(); p2[f, k, 24] ^= 0x01                        # one character of its text, pipeline form only
+    c, fb = run(pipe_=p2)
+    assert c["records_differing_pipeline_form"] == 1 and c["records_differing_stage_form"] == 0
+    bad = np.argwhere((st[:, :, 9] == 0) & (np.arange(cap)[None, :] < counts[:, None]))
+    fb_, kb_ = map(int, bad[0])
+    p3 = pipe.copy(); p3[fb_, kb_, 0:2].view(np.int16)[...] = 7   # a count the pipeline form never reports
+    c, _ = run(pipe_=p3)
+    assert c["pipeline_form_ldpc_errors_not_0_or_83"] == 1 and c["records_differing_pipeline_form"] == 0
+    p4 = pipe.copy(); p4[fb_, kb_, 0:2].view(np.int16)[...] = 0   # "converged" where the oracle did not
+    c, _ = run(pipe_=p4)
+    assert c["records_differing_pipeline_form"] == 1
+    s5 = st.copy(); s5[0, cap - 1, 30] = 0x41 if counts[0] < cap else s5[0, cap - 1, 30]
+    if counts[0] < cap:                                           # a byte behind the last candidate's record
+        c, _ = run(st_=s5)
+        assert c["records_differing_stage_form"] == 1
+    with pytest.raises(AssertionError, match="stage boundaries differ"):
+        stage_check.assert_clean(c if counts[0] < cap else run(st_=s2)[0], "doctored")
