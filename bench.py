@@ -539,6 +539,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or args.force_dist
+    if use_dist:
+        # read by the HSA runtime when the process first touches the GPU (the decoder context is created before the process
+        # group): the host driver of this pool only supports dmabuf IPC, without it RCCL fails with hipIpcGetMemHandle errors
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # the watchdog child exists before this process imports torch or touches the GPU (multi-rank / forced-dist runs only)
     wd = RankWatchdog(rank, world, use_dist, args.dist_timeout)
     hang, hang_limit = _hang_spec(args.test_hang)
