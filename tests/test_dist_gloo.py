@@ -272,3 +272,19 @@ def test_bench_no_exchange_control_leg_and_rank_identities_in_the_line():
     info = lines[0]["ranks_info"]
     assert sorted(info) == ["0", "1"] and info["0"]["pid"] != info["1"]["pid"] and {v["local_rank"] for v in info.values()} == {0, 1}
     assert sorted(lines[0]["per_rank_decode_only"]) == ["0", "1"]
+
+
+def test_scaling_curve_tool_runs_both_legs_per_world_size():
+    """tools/scaling_curve.py: the one command for the first multi-GPU node -- per N a run with the gather and a --no-exchange
+    control run, efficiencies against the first row, gather cost, failure lines; here on gloo with pattern records"""
+    import json
+    import subprocess
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scaling_curve.py"), "--gpus", "1", "2", "--dry", "--frames", "24",
+                        "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert p.returncode == 0, p.stderr[-1500:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert [r["n_gpus"] for r in d["curve"]] == [1, 2] and d["dry"] is True
+    two = d["curve"][1]
+    assert two["with_gather"]["frames_per_s"] > 0 and two["no_exchange"]["frames_per_s"] > 0 and two["gather_cost_frac"] is not None
+    assert two["with_gather"]["efficiency_vs_first_row"] is not None and not two["with_gather"]["failures"]
