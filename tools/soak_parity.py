@@ -28,6 +28,10 @@ def main():
                     help="draw the number of frames of each batch log-uniformly from 1 ... --frames (and once in eight exactly at a threshold of the "
                          "pipeline: 511, 512, 513, 1024, 1025, 2048, 2049): the plain and the two-part pipeline, the part split, the heap kernel forms "
                          "chosen by launch size and the 1024-frame chunks of the stage comparison all depend on it")
+    ap.add_argument("--wide-caps", action="store_true",
+                    help="draw K_MAX_CANDIDATES per batch from the whole accepted range instead of 60 ... 480: 1, 2, 7, 33, 120, 481, 777, 1024 "
+                         "(FT8GPU_ABS_MAX_CANDIDATES; the reference fixes 120, rtlsdr_ft8d.h:44): a heap of one entry, caps off the 4-candidate "
+                         "block grid of the LDPC launch, and the largest list the context accepts")
     ap.add_argument("--vary-iters", action="store_true",
                     help="draw K_LDPC_ITERS per batch from 20, 20, 1, 5, 13, 50 on both sides (the reference fixes 20, rtlsdr_ft8d.h:45, and passes it "
                          "at rtlsdr_ft8d.c:1476; the kernel's iteration loop, its skipped dead last update and the iteration field of the status "
@@ -69,7 +73,7 @@ def main():
     for b in range(args.batches):
         nsig = int(rng.integers(0, 61))
         lo_snr = float(rng.uniform(-26, -10)); hi_snr = lo_snr + float(rng.uniform(2, 20))
-        cap = int(rng.choice([120, 120, 120, 60, 240, 480]))
+        cap = int(rng.choice([1, 2, 7, 33, 120, 481, 777, 1024])) if args.wide_caps else int(rng.choice([120, 120, 120, 60, 240, 480]))
         min_score = int(rng.choice([10, 10, 5, 0, -3, 20, 30])) if args.vary_min_score else 10
         iters = int(rng.choice([20, 20, 1, 5, 13, 50])) if args.vary_iters else 20
         if args.vary_frames:
@@ -102,7 +106,7 @@ def main():
     print(json.dumps({"frames": total, "messages": msgs, "cq_spots_written": written, "mismatching_frames": bad, "seconds": round(time.time() - t0, 1), "seed": args.seed,
                       "batches": args.batches, "traffic": args.traffic, "edges": bool(args.edges), "vary_min_score": bool(args.vary_min_score), "initial_record_byte": fill, "messages_per_frame": round(msgs / max(total, 1), 3),
                       "cq_spots_per_frame": round(written / max(total, 1), 3), "build_id": build_id,
-                      "vary_iters": bool(args.vary_iters), "vary_frames": bool(args.vary_frames), **({"batch_sizes_min_median_max": [int(min(sizes)), int(np.median(sizes)), int(max(sizes))], "batches_below_512_frames": int(sum(x < 512 for x in sizes))} if sizes else {}), "frames_by_ldpc_iters": {str(k): v for k, v in sorted(iters_hist.items())},
+                      "vary_iters": bool(args.vary_iters), "vary_frames": bool(args.vary_frames), "wide_caps": bool(args.wide_caps), **({"batch_sizes_min_median_max": [int(min(sizes)), int(np.median(sizes)), int(max(sizes))], "batches_below_512_frames": int(sum(x < 512 for x in sizes))} if sizes else {}), "frames_by_ldpc_iters": {str(k): v for k, v in sorted(iters_hist.items())},
                       **({"stages": stages, "stage_differences_total": stage_check.differing(stages), "first_differences": first_bad} if args.records else {})}))
     return 1 if bad or (args.records and stage_check.differing(stages)) else 0
 
