@@ -28,6 +28,11 @@ def main():
                     help="draw the number of frames of each batch log-uniformly from 1 ... --frames (and once in eight exactly at a threshold of the "
                          "pipeline: 511, 512, 513, 1024, 1025, 2048, 2049): the plain and the two-part pipeline, the part split, the heap kernel forms "
                          "chosen by launch size and the 1024-frame chunks of the stage comparison all depend on it")
+    ap.add_argument("--vary-gain", action="store_true",
+                    help="scale the frames of two batches in three by 10^U(-4, 2.5) (the same float32 product on both sides): the log-magnitude "
+                         "quantiser (rtlsdr_ft8d.c:1413-1433) then works all over its range and into both clamps -- 0 below -120 dB, 255 above "
+                         "+7.5 dB -- where the device's threshold table stands in for log10f; partly or wholly saturated waterfalls also give "
+                         "candidates whose LLRs are all zero (variance 0: the scale factor is inf, the LLRs NaN, as in the reference)")
     ap.add_argument("--wide-caps", action="store_true",
                     help="draw K_MAX_CANDIDATES per batch from the whole accepted range instead of 60 ... 480: 1, 2, 7, 33, 120, 481, 777, 1024 "
                          "(FT8GPU_ABS_MAX_CANDIDATES; the reference fixes 120, rtlsdr_ft8d.h:44): a heap of one entry, caps off the 4-candidate "
@@ -55,6 +60,7 @@ def main():
     build_id = ft8.check_build_id()               # a stale or foreign library is refused before anything is measured
     B = BMAX = args.frames
     sizes = []
+    gains = []
     mixed = args.traffic == "mixed"
     _, tones = workload.message_pool(traffic=args.traffic)
     fill = 0xA5 if mixed else 0
@@ -86,6 +92,12 @@ def main():
                                         dup_fraction=workload.MIXED_DUP_FRACTION if mixed else 0.0,
                                         **(dict(f_range=(-20.0, 1620.0), dt_range=(-1.5, 3.0)) if args.edges else {}))
         dec.synth_frames(sig, B, nsig, 1.0, 777 + b + (args.seed - 123) * 100_003, iq)
+        gain = 1.0
+        if args.vary_gain and rng.integers(0, 3) != 0:
+            gain = float(10.0 ** rng.uniform(-4.0, 2.5))
+            dec.synchronize()                            # the synthesis runs on the decoder's stream, the scaling on torch's
+            iq.mul_(gain)
+            gains.append(gain)
         spots.fill_(fill)
         torch.cuda.synchronize()                     # the fill runs on torch's stream, the decoder on its own
         dec.decode_batch_dev(iq, B, spots, nres)
@@ -102,11 +114,11 @@ def main():
                 print(f"batch {b}: stage boundaries differ: {stages} first {first_bad}", flush=True)
         w = int(sum(1 for k in range(B) for j in range(min(int(gn[k]), 50)) if g[k, j].tobytes() != stale_rec)) if mixed else int(np.minimum(gn, 50).sum())
         bad += len(mism); total += B; msgs += int(gn.sum()); written += w
-        print(f"batch {b}: {B} frames, nsig {nsig} snr [{lo_snr:.0f},{hi_snr:.0f}] cap {cap} min_score {min_score} iters {iters}: {int(gn.sum())} messages, {w} CQ spots, mismatching frames {len(mism)}", flush=True)
+        print(f"batch {b}: {B} frames, nsig {nsig} snr [{lo_snr:.0f},{hi_snr:.0f}] cap {cap} min_score {min_score} iters {iters} gain {gain:.3g}: {int(gn.sum())} messages, {w} CQ spots, mismatching frames {len(mism)}", flush=True)
     print(json.dumps({"frames": total, "messages": msgs, "cq_spots_written": written, "mismatching_frames": bad, "seconds": round(time.time() - t0, 1), "seed": args.seed,
                       "batches": args.batches, "traffic": args.traffic, "edges": bool(args.edges), "vary_min_score": bool(args.vary_min_score), "initial_record_byte": fill, "messages_per_frame": round(msgs / max(total, 1), 3),
                       "cq_spots_per_frame": round(written / max(total, 1), 3), "build_id": build_id,
-                      "vary_iters": bool(args.vary_iters), "vary_frames": bool(args.vary_frames), "wide_caps": bool(args.wide_caps), **({"batch_sizes_min_median_max": [int(min(sizes)), int(np.median(sizes)), int(max(sizes))], "batches_below_512_frames": int(sum(x < 512 for x in sizes))} if sizes else {}), "frames_by_ldpc_iters": {str(k): v for k, v in sorted(iters_hist.items())},
+                      "vary_iters": bool(args.vary_iters), "vary_frames": bool(args.vary_frames), "wide_caps": bool(args.wide_caps), "vary_gain": bool(args.vary_gain), **({"gains_min_max": [min(gains), max(gains)], "batches_scaled": len(gains)} if gains else {}), **({"batch_sizes_min_median_max": [int(min(sizes)), int(np.median(sizes)), int(max(sizes))], "batches_below_512_frames": int(sum(x < 512 for x in sizes))} if sizes else {}), "frames_by_ldpc_iters": {str(k): v for k, v in sorted(iters_hist.items())},
                       **({"stages": stages, "stage_differences_total": stage_check.differing(stages), "first_differences": first_bad} if args.records else {})}))
     return 1 if bad or (args.records and stage_check.differing(stages)) else 0
 
