@@ -175,8 +175,10 @@ void ft8_decode_kernel(const uint8_t *__restrict__ mag, const ft8gpu_candidate *
     const unsigned nb = gridDim.x, per = nb >> 3, main_blocks = per << 3;
     const unsigned vb = blockIdx.x < main_blocks ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
     // vb = frame * blocks_per_frame + group; bpf_magic = floor(2^32 / blocks_per_frame) + 1 makes the
-    // quotient one multiply-high (exact for vb * blocks_per_frame < 2^32, checked at launch)
-    const int frame = (int)__umulhi(vb, bpf_magic);
+    // quotient one multiply-high (exact for vb * blocks_per_frame < 2^32, checked at launch).  One block per frame
+    // (max_candidates <= 4) has no such constant -- 2^32 + 1 does not fit 32 bits; as the truncated 1 it sent every block to
+    // frame 0, found in round 6 by a soak over the whole accepted range of max_candidates -- and needs no division.
+    const int frame = blocks_per_frame == 1u ? (int)vb : (int)__umulhi(vb, bpf_magic);
     const int ci = (int)(vb - (unsigned)frame * blocks_per_frame) * 4 + wave;
     if (frame >= nframes || ci >= max_candidates) return;
     if (ci >= counts[frame]) return;                        // wave-uniform
@@ -620,7 +622,7 @@ hipError_t launch_decode(const uint8_t *mag, const ft8gpu_candidate *cands, cons
     const unsigned bpf = (unsigned)(max_candidates + 3) / 4;                  // blocks (of 4 candidate waves) per frame
     const unsigned long long nblocks = (unsigned long long)nframes * bpf;
     if (nblocks * bpf >= (1ull << 32)) return hipErrorInvalidValue;           // keeps the multiply-high division exact
-    const unsigned magic = (unsigned)((1ull << 32) / bpf) + 1u;
+    const unsigned magic = bpf == 1u ? 0u : (unsigned)((1ull << 32) / bpf) + 1u;          // bpf >= 2: at most 2^31 + 1
     if (count_errors)
         hipLaunchKernelGGL((ft8_decode_kernel<true, 1>), dim3((unsigned)nblocks), dim3(256), 0, s,
                            mag, cands, counts, status, nframes, max_candidates, ldpc_iters, force_ieee_div, bpf, magic);

@@ -388,3 +388,33 @@ def test_ldpc_iteration_caps_other_than_20_at_every_stage_boundary(oracle, iters
     stage_check.assert_clean(sc, f"ldpc_iters {iters}", first_bad)
     # the cap really bites: fewer decodes at 1 iteration than the about 12 per frame of 20, more than none
     assert (2 if iters == 1 else 8) * B < int(n1.sum()) < 14 * B, int(n1.sum())
+
+
+@pytest.mark.parametrize("cap", [1, 2, 3, 4, 5, 777, 1024])
+def test_candidate_caps_at_both_ends_of_the_accepted_range(oracle, cap):
+    """ft8gpu_params.max_candidates is accepted from 1 to FT8GPU_ABS_MAX_CANDIDATES = 1024 (the reference fixes 120,
+    rtlsdr_ft8d.h:44).  Up to four candidates the LDPC launch has ONE 4-wave block per frame, and the multiply-high constant
+    that turns a block index into a frame index does not exist for a divisor of 1 (2^32 + 1): truncated to 1 it sent every block
+    to frame 0, so every frame but the first of a batch came back without a decode -- found in round 6 by the soak over the
+    whole range (tools/soak_parity.py --wide-caps), never by a test, because no test had more than one frame at such a cap.
+    Whole path and every stage boundary in both kernel forms, several hundred frames, both ends of the range."""
+    import torch
+    import rtlsdr_ft8d_amd as ft8
+    from rtlsdr_ft8d_amd import workload
+    B, S = (640, 12) if cap <= 5 else (96, 30)                    # 640: the two-part pipeline; the long lists cost the oracle more
+    _, tones = workload.message_pool(traffic="mixed")
+    with ft8.Decoder(device=0, max_frames=B, max_candidates=max(cap, 120)) as dec:
+        dec.set_params(max_candidates=cap, min_score=0 if cap > 5 else 10)
+        min_score = 0 if cap > 5 else 10                           # at 0 every position of the scan survives: the long caps fill up
+        sig, _ = workload.frame_signals(800000 + cap * 1000, B, S, tones, snr_range=(-16.0, 0.0), dup_fraction=workload.MIXED_DUP_FRACTION)
+        iq = torch.empty((B, 2, ft8.NSAMPLES), dtype=torch.float32, device="cuda")
+        dec.synth_frames(sig, B, S, 1.0, workload.SEED_BASE + 60 + cap, iq, first_frame=800000 + cap * 1000)
+        d1, n1 = _decode_dev(ft8, dec, iq, B, fill=0xA5)
+        rdec, rn = _oracle_all(oracle, iq, oracle.default_params(min_score, cap, 20), fill=0xA5)
+        first_bad = []
+        sc = stage_check.stage_boundaries_vs_oracle(ft8, oracle, dec, iq, B, cap, min_score, 20, _host_threads(), first_bad=first_bad)
+    _assert_frames_equal(d1, n1, rdec, rn, f"max_candidates {cap}")
+    stage_check.assert_clean(sc, f"max_candidates {cap}", first_bad)
+    assert sc["candidate_records"] == (B * cap if cap > 5 else sc["candidate_records"]) and sc["candidate_records"] >= 0.9 * B * min(cap, 5)
+    assert int(n1.sum()) > (0.3 * B if cap <= 5 else 5 * B), int(n1.sum())      # frames beyond the first really decode
+    assert int((n1[1:] > 0).sum()) > 0.25 * (B - 1)
