@@ -41,6 +41,9 @@ def main():
                     help="draw K_LDPC_ITERS per batch from 20, 20, 1, 5, 13, 50 on both sides (the reference fixes 20, rtlsdr_ft8d.h:45, and passes it "
                          "at rtlsdr_ft8d.c:1476; the kernel's iteration loop, its skipped dead last update and the iteration field of the status "
                          "record must follow upstream's bp_decode at any cap)")
+    ap.add_argument("--wide-iters", action="store_true",
+                    help="draw K_LDPC_ITERS from 1, 2, 3, 19, 20, 21, 50, 137, 1000 (the accepted range is 1 ... 1000; use small batches: a "
+                         "candidate that never converges costs the oracle fifty times the usual at 1000)")
     ap.add_argument("--records", "--stages", action="store_true", dest="records",
                     help="also compare every stage boundary of every frame through the stage entries: all 94 208 waterfall bytes, the ordered "
                          "candidate list, and the 48-byte status record of EVERY candidate (parity errors, iterations, packed bits, CRCs, unpack "
@@ -82,6 +85,8 @@ def main():
         cap = int(rng.choice([1, 2, 7, 33, 120, 481, 777, 1024])) if args.wide_caps else int(rng.choice([120, 120, 120, 60, 240, 480]))
         min_score = int(rng.choice([10, 10, 5, 0, -3, 20, 30])) if args.vary_min_score else 10
         iters = int(rng.choice([20, 20, 1, 5, 13, 50])) if args.vary_iters else 20
+        if args.wide_iters:
+            iters = int(rng.choice([1, 2, 3, 19, 20, 21, 50, 137, 1000]))
         if args.vary_frames:
             B = int(rng.choice([511, 512, 513, 1024, 1025, 2048, 2049])) if rng.integers(0, 8) == 0 else int(round(float(np.exp(rng.uniform(0.0, np.log(BMAX))))))
             B = max(1, min(B, BMAX))
@@ -118,7 +123,7 @@ def main():
     print(json.dumps({"frames": total, "messages": msgs, "cq_spots_written": written, "mismatching_frames": bad, "seconds": round(time.time() - t0, 1), "seed": args.seed,
                       "batches": args.batches, "traffic": args.traffic, "edges": bool(args.edges), "vary_min_score": bool(args.vary_min_score), "initial_record_byte": fill, "messages_per_frame": round(msgs / max(total, 1), 3),
                       "cq_spots_per_frame": round(written / max(total, 1), 3), "build_id": build_id,
-                      "vary_iters": bool(args.vary_iters), "vary_frames": bool(args.vary_frames), "wide_caps": bool(args.wide_caps), "vary_gain": bool(args.vary_gain), **({"gains_min_max": [min(gains), max(gains)], "batches_scaled": len(gains)} if gains else {}), **({"batch_sizes_min_median_max": [int(min(sizes)), int(np.median(sizes)), int(max(sizes))], "batches_below_512_frames": int(sum(x < 512 for x in sizes))} if sizes else {}), "frames_by_ldpc_iters": {str(k): v for k, v in sorted(iters_hist.items())},
+                      "vary_iters": bool(args.vary_iters), "vary_frames": bool(args.vary_frames), "wide_caps": bool(args.wide_caps), "wide_iters": bool(args.wide_iters), "vary_gain": bool(args.vary_gain), **({"gains_min_max": [min(gains), max(gains)], "batches_scaled": len(gains)} if gains else {}), **({"batch_sizes_min_median_max": [int(min(sizes)), int(np.median(sizes)), int(max(sizes))], "batches_below_512_frames": int(sum(x < 512 for x in sizes))} if sizes else {}), "frames_by_ldpc_iters": {str(k): v for k, v in sorted(iters_hist.items())},
                       **({"stages": stages, "stage_differences_total": stage_check.differing(stages), "first_differences": first_bad} if args.records else {})}))
     return 1 if bad or (args.records and stage_check.differing(stages)) else 0
 
