@@ -418,3 +418,35 @@ def test_candidate_caps_at_both_ends_of_the_accepted_range(oracle, cap):
     assert sc["candidate_records"] == (B * cap if cap > 5 else sc["candidate_records"]) and sc["candidate_records"] >= 0.9 * B * min(cap, 5)
     assert int(n1.sum()) > (0.3 * B if cap <= 5 else 5 * B), int(n1.sum())      # frames beyond the first really decode
     assert int((n1[1:] > 0).sum()) > 0.25 * (B - 1)
+
+
+def test_one_call_of_40960_frames_equals_ten_calls_of_4096():
+    """288 GB of HBM hold far larger batches than BASELINE's 4096 per GPU; nothing in the configs exercises the index arithmetic
+    of a context beyond that (compact lists alone are 7.8 GB at 40 960 frames: byte offsets pass 2^32).  One call on a 40 960-frame
+    context must give, frame for frame, what ten 4096-frame calls on the same frames give."""
+    import torch
+    import rtlsdr_ft8d_amd as ft8
+    from rtlsdr_ft8d_amd import workload
+    F, P = 40960, 4096
+    _, tones = workload.message_pool()
+    with ft8.Decoder(device=0, max_frames=F) as big, ft8.Decoder(device=0, max_frames=P) as small:
+        iq = torch.empty((F, 2, ft8.NSAMPLES), dtype=torch.float32, device="cuda")
+        for lo in range(0, F, P):                                  # distinct frames throughout (aliasing must not hide anything)
+            sig, _ = workload.frame_signals(2_000_000 + lo, P, 12, tones, snr_range=(-17.0, -2.0))
+            small.synth_frames(sig, P, 12, 1.0, workload.SEED_BASE + 77, iq[lo:lo + P], first_frame=2_000_000 + lo)
+        small.synchronize()
+        spots = torch.zeros((F, 1400), dtype=torch.uint8, device="cuda")
+        nres = torch.zeros((F,), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        big.decode_batch_dev(iq, F, spots, nres)
+        big.synchronize()
+        one = (spots.cpu().numpy(), nres.cpu().numpy())
+        spots.zero_(); nres.zero_()
+        torch.cuda.synchronize()
+        for lo in range(0, F, P):
+            small.decode_batch_dev(iq[lo:lo + P], P, spots[lo:lo + P], nres[lo:lo + P])
+        small.synchronize()
+        ten = (spots.cpu().numpy(), nres.cpu().numpy())
+    bad = np.flatnonzero((one[1] != ten[1]) | (one[0] != ten[0]).any(axis=1))
+    assert bad.size == 0, f"{bad.size} of {F} frames differ between one call and ten, first {bad[:8]}"
+    assert int(one[1].sum()) > 5 * F and int((one[1][-P:] > 0).sum()) > 0.9 * P      # the last chunk decodes like the first

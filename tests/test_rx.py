@@ -93,3 +93,26 @@ def test_gpu_rx_feeds_decoder(oracle, gpu_decoder):
     i, q, _ = oracle.rx_capture(raw[0], normalise=True)
     rdec, rn = oracle.subsystem(i, q)
     assert n[0] == rn and dec[0].tobytes() == rdec.tobytes()
+
+
+@pytest.mark.gpu
+def test_gpu_rx_batch_whose_raw_bytes_pass_4_gib(oracle):
+    """62 full-length captures in one launch are 4.46 GB of raw bytes: captures 59 (whose bytes straddle offset 2^32) and 61
+    (wholly beyond it) must come out as the sequential oracle computes them -- the 64-capture bench of round 4 only ever
+    compared capture 0 (tools/bench_rx.py), and the RX soak runs 16 captures per launch."""
+    import torch
+    import rtlsdr_ft8d_amd as ft8
+    ncap, npairs = 62, 36_000_000
+    g = torch.Generator(device="cuda").manual_seed(11)
+    raw = torch.randint(0, 256, (ncap, 2 * npairs), dtype=torch.uint8, device="cuda", generator=g)
+    assert raw.numel() > (1 << 32) and 59 * 2 * npairs < (1 << 32) < 60 * 2 * npairs
+    iq = torch.empty((ncap, 2, ft8.NSAMPLES), dtype=torch.float32, device="cuda")
+    with ft8.Decoder(device=0, max_frames=ncap) as dec:
+        torch.cuda.synchronize()
+        dec.rx_decimate_dev(raw, ncap, npairs, iq, True)
+        dec.synchronize()
+    for k in (0, 59, 61):
+        i, q, n = oracle.rx_capture(raw[k].cpu().numpy(), normalise=True)
+        got = iq[k].cpu().numpy()
+        assert n == 47936
+        assert np.array_equal(got[0].view(np.uint32), i.view(np.uint32)) and np.array_equal(got[1].view(np.uint32), q.view(np.uint32)), f"capture {k} differs"
