@@ -12,7 +12,11 @@
                   place, with ft8_subsystem calls (same global context, other parameters) in between.  ft8_decode must stay the
                   pure function of (waterfall bytes, candidate, max_iterations) that upstream's is: every answer against the oracle.
 
-usage: tools/soak_entries.py --entry host|dropin|ft8lib [--frames N] [--seed S]"""
+  --entry multi   the multi-GPU entries with several contexts on the one GPU of the box: ft8gpu_decode_batch_multi (one host array cut
+                  into contiguous shards) and ft8gpu_decode_batch_multi_dev (device-resident shards of ANY sizes, empty ones included),
+                  1 ... 6 contexts, ragged totals, patterned caller records -- every frame against the oracle
+
+usage: tools/soak_entries.py --entry host|dropin|ft8lib|multi [--frames N] [--seed S]"""
 import argparse, ctypes as C, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,7 +34,7 @@ def synth(ft8, workload, dec, torch, first, n, nsig, snr, tones, seed_off, edges
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--entry", choices=("host", "dropin", "ft8lib"), required=True)
+    ap.add_argument("--entry", choices=("host", "dropin", "ft8lib", "multi"), required=True)
     ap.add_argument("--frames", type=int, default=20000, help="frames in total (ft8lib: waterfalls)")
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
@@ -86,6 +90,53 @@ def main():
                 msgs += int(k)
             done += n; b += 1
         out.update({"frames": done, "messages": msgs, "mismatching_frames": bad})
+
+    elif args.entry == "multi":
+        P = 1024
+        pool = [ft8.Decoder(device=0, max_frames=P) for _ in range(6)]
+        b = 0
+        shapes = {}
+        while done < args.frames:
+            ndev = int(rng.integers(1, 7))
+            decs = pool[:ndev]
+            cap = int(rng.choice([2, 33, 120, 120, 480]))
+            iters = int(rng.choice([20, 20, 7]))
+            for d_ in decs:
+                d_.set_params(min_score=10, max_candidates=cap, ldpc_iters=iters)
+            nsig = int(rng.integers(0, 40))
+            prm = O.default_params(10, cap, iters)
+            if rng.integers(0, 2) == 0:                                      # one host array, shards cut by the library
+                n = int(rng.integers(0, ndev * P + 1)) if rng.integers(0, 6) else int(rng.integers(0, ndev + 2))
+                n = max(n, 1)
+                iq = np.concatenate([synth(ft8, workload, gen, torch, 9_000_000 + args.seed * 10_000_000 + b * 8192 + lo, min(4096, n - lo), nsig, (-19.0, 0.0), tones, 800 + b, False)
+                                     for lo in range(0, n, 4096)])
+                start = np.full((n, 1400), FILL, np.uint8).view(ft8.RESULT_DTYPE).reshape(n, 50)
+                d, k = ft8.decode_batch_multi(decs, iq, decodes=start.copy())
+                form = "host array"
+            else:                                                            # device-resident shards of any sizes
+                counts = [int(rng.integers(0, P + 1)) if rng.integers(0, 5) else 0 for _ in range(ndev)]
+                if sum(counts) == 0:
+                    counts[int(rng.integers(0, ndev))] = int(rng.integers(1, P + 1))
+                n = sum(counts)
+                iq = np.concatenate([synth(ft8, workload, gen, torch, 9_000_000 + args.seed * 10_000_000 + b * 8192 + lo, min(4096, n - lo), nsig, (-19.0, 0.0), tones, 800 + b, False)
+                                     for lo in range(0, n, 4096)])
+                devs, lo = [], 0
+                for c_ in counts:
+                    devs.append(torch.from_numpy(iq[lo:lo + c_]).cuda() if c_ else None)
+                    lo += c_
+                torch.cuda.synchronize()
+                start = np.full((n, 1400), FILL, np.uint8).view(ft8.RESULT_DTYPE).reshape(n, 50)
+                d, k = ft8.decode_batch_multi_dev(decs, devs, counts, decodes=start.copy())
+                form = "device shards"
+            rdec, rn = O.subsystem_batch(iq, prm, cores, decodes=start.copy().view(O.RESULT_DTYPE).reshape(n, 50))
+            mism = int(sum(1 for f in range(n) if k[f] != rn[f] or d[f].tobytes() != rdec[f].tobytes()))
+            if mism:
+                print(f"call {b}: {form}, {ndev} contexts, {n} frames, cap {cap}: {mism} frames differ", flush=True)
+            bad += mism; done += n; msgs += int(k.sum()); b += 1
+            shapes[f"{form} x{ndev}"] = shapes.get(f"{form} x{ndev}", 0) + 1
+        for d_ in pool:
+            d_.close()
+        out.update({"frames": done, "calls": b, "messages": msgs, "mismatching_frames": bad, "calls_by_form_and_contexts": dict(sorted(shapes.items()))})
 
     else:
         class Waterfall(C.Structure):
