@@ -16,7 +16,10 @@
                   into contiguous shards) and ft8gpu_decode_batch_multi_dev (device-resident shards of ANY sizes, empty ones included),
                   1 ... 6 contexts, ragged totals, patterned caller records -- every frame against the oracle
 
-usage: tools/soak_entries.py --entry host|dropin|ft8lib|multi [--frames N] [--seed S]"""
+  --entry report  ft8gpu_pskreporter_datagrams (postSpots' datagram bytes, rtlsdr_ft8d.c:365-590) on random record lists -- stale caller
+                  bytes, unterminated fields, 0 ... 50 spots, the 1200-byte cut, per-frame times -- every datagram against the oracle
+
+usage: tools/soak_entries.py --entry host|dropin|ft8lib|multi|report [--frames N] [--seed S]"""
 import argparse, ctypes as C, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -34,7 +37,7 @@ def synth(ft8, workload, dec, torch, first, n, nsig, snr, tones, seed_off, edges
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--entry", choices=("host", "dropin", "ft8lib", "multi"), required=True)
+    ap.add_argument("--entry", choices=("host", "dropin", "ft8lib", "multi", "report"), required=True)
     ap.add_argument("--frames", type=int, default=20000, help="frames in total (ft8lib: waterfalls)")
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
@@ -90,6 +93,26 @@ def main():
                 msgs += int(k)
             done += n; b += 1
         out.update({"frames": done, "messages": msgs, "mismatching_frames": bad})
+
+    elif args.entry == "report":
+        import test_report as TR
+        longest = 0
+        while done < args.frames:
+            F = int(rng.choice([1, 63, 64, 65, 1000, 4096]))
+            d, n = TR._random_lists(O, rng, max(F, 4))
+            d, n = d[:F], n[:F]
+            times = rng.integers(0, 2**32, F, dtype=np.uint64).astype(np.uint32)
+            info = TR._info(ft8.ReportInfo, rcall=b"VE2XYZ/QRP12", rloc=b"FN35ab", app=b"rtlsdr-ft8d_v0.3.6", dial=int(rng.integers(0, 2**32)))
+            dial = info.dial_freq
+            outb, lens = gen.pskreporter_datagrams(d.view(ft8.RESULT_DTYPE), n, info, times)
+            for f in range(F):
+                oi = TR._info(O.ReportInfo, rcall=b"VE2XYZ/QRP12", rloc=b"FN35ab", app=b"rtlsdr-ft8d_v0.3.6", dial=dial, now=int(times[f]))
+                want = O.pskreporter_datagram(d[f], max(0, int(n[f])), oi)
+                if lens[f] != want.size or outb[f, :lens[f]].tobytes() != want.tobytes() or outb[f, lens[f]:].any():
+                    bad += 1
+                longest = max(longest, int(want.size))
+            done += F
+        out.update({"frames": done, "mismatching_frames": bad, "longest_datagram_bytes": longest})
 
     elif args.entry == "multi":
         P = 1024
