@@ -587,3 +587,74 @@ def test_failed_buffer_growth_leaves_the_context_as_it_was():
         dec.synchronize()
         assert (spots.cpu().numpy().tobytes(), nres.cpu().numpy().tobytes()) == before
         assert int(nres.sum().item()) > 8 * n
+
+
+def test_device_outputs_stay_inside_their_buffers():
+    """Every device-pointer entry writes into caller-owned HBM.  A write one element past a buffer would corrupt whatever the
+    caller keeps next to it and no parity test would notice: here every output buffer is a slice of ONE allocation with 4 KB of
+    0xEE on either side, sizes are ragged (513 frames, cap 7, a capture of 751 * 3000 + 8 * 37 pairs), and every guard byte must
+    survive the batch entry, the four stage entries, the RX front end, the report stage and the synthesiser."""
+    import torch
+    import rtlsdr_ft8d_amd as ft8
+    from rtlsdr_ft8d_amd import workload
+    G = 4096
+    n, cap = 513, 7
+
+    class Arena:
+        def __init__(self, total):
+            self.buf = torch.full((total,), 0xEE, dtype=torch.uint8, device="cuda")
+            self.off, self.slices = 0, []
+
+        def take(self, nbytes, dtype=torch.uint8):
+            self.off += G                                                   # guard in front
+            self.off = (self.off + 255) // 256 * 256
+            a = self.buf[self.off:self.off + nbytes]
+            self.slices.append((self.off, nbytes))
+            self.off += nbytes
+            return a.view(dtype)
+
+        def guards_intact(self):
+            mask = torch.ones_like(self.buf, dtype=torch.bool)
+            for o, k in self.slices:
+                mask[o:o + k] = False
+            return bool((self.buf[mask] == 0xEE).all())
+
+    ar = Arena(400 << 20)
+    iq = ar.take(n * 2 * ft8.NSAMPLES * 4, torch.float32).view(n, 2, ft8.NSAMPLES)
+    spots = ar.take(n * 1400)
+    nres = ar.take(n * 4, torch.int32)
+    mag = ar.take(n * ft8.MAG_ARRAY).view(n, ft8.MAG_ARRAY)
+    cands = ar.take(n * cap * 8)
+    counts = ar.take(n * 4, torch.int32)
+    status = ar.take(n * cap * 48)
+    grams = ar.take(n * ft8.DATAGRAM_STRIDE)
+    glen = ar.take(n * 4, torch.int32)
+    times = ar.take(n * 4, torch.int32)
+    npairs = 751 * 3000 + 8 * 37
+    npairs -= npairs % 8
+    ncap = 3
+    raw = ar.take(ncap * 2 * npairs)
+    rx_iq = ar.take(ncap * 2 * ft8.NSAMPLES * 4, torch.float32)
+    assert ar.off + G < ar.buf.numel()
+    _, tones = workload.message_pool(traffic="mixed")
+    sig, _ = workload.frame_signals(950000, n, 15, tones, snr_range=(-15.0, 0.0))
+    raw.copy_(torch.randint(0, 256, (raw.numel(),), dtype=torch.uint8, device="cuda"))
+    times.zero_()
+    with ft8.Decoder(device=0, max_frames=n, max_candidates=120) as dec:
+        dec.set_params(max_candidates=cap)
+        torch.cuda.synchronize()
+        dec.synth_frames(sig, n, 15, 1.0, workload.SEED_BASE + 91, iq, first_frame=950000)
+        dec.decode_batch_dev(iq, n, spots, nres)
+        dec.waterfall_dev(iq, n, mag)
+        dec.find_sync_dev(mag, n, cands, counts)
+        dec.decode_candidates_dev(mag, cands, counts, n, status)
+        dec.set_debug_flags(ft8.DBG_PIPELINE_FORM)
+        dec.decode_candidates_dev(mag, cands, counts, n, status)
+        dec.set_debug_flags(0)
+        dec.rx_decimate_dev(raw, ncap, npairs, rx_iq, True)
+        info = ft8.ReportInfo(rcall=b"N0CALL", rloc=b"FN20", app_version=b"rtlsdr-ft8d_v0.3.6", dial_freq=14074000, unixtime=1700000000, sequence=1, random_id=7)
+        dec.pskreporter_datagrams_dev(spots, nres, n, info, times, grams, glen)
+        dec.synchronize()
+    torch.cuda.synchronize()
+    assert int(nres.sum().item()) > 2 * n and int(counts.sum().item()) > 5 * n and int(glen.sum().item()) > 100 * n     # the entries really ran
+    assert ar.guards_intact(), "a device-pointer entry wrote outside the buffer it was given"
