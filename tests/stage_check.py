@@ -58,9 +58,10 @@ def compare_with_oracle(O, iq_host, h_mag, h_cands, h_counts, g_stage, g_pipe, c
     return c
 
 
-def stage_boundaries_vs_oracle(ft8, O, dec, iq, nframes, cap, min_score, iters, cores, counters=None, chunk=1024, first_bad=None):
+def stage_boundaries_vs_oracle(ft8, O, dec, iq, nframes, cap, min_score, iters, cores, counters=None, chunk=1024, first_bad=None, base_flags=0):
     """iq: [nframes][2][48000] float32 on the device; dec's parameters must already be (min_score, cap, iters) and cap must not
-    exceed what dec was created / set for (the context's debug flags are left at 0).  Adds to `counters` (new_counters()) and
+    exceed what dec was created / set for.  base_flags: the FT8GPU_DBG_* bits the context runs with (both passes keep them; they are
+    what the context is left with).  Adds to `counters` (new_counters()) and
     returns it; `first_bad` (a list) receives up to 8 (stage, frame, candidate) tuples."""
     import torch
     c = counters if counters is not None else new_counters()
@@ -77,12 +78,12 @@ def stage_boundaries_vs_oracle(ft8, O, dec, iq, nframes, cap, min_score, iters, 
         dec.find_sync_dev(mag, m, cands, counts)
         dec.decode_candidates_dev(mag, cands, counts, m, st_stage)
         dec.synchronize()
-        dec.set_debug_flags(ft8.DBG_PIPELINE_FORM)
+        dec.set_debug_flags(base_flags | ft8.DBG_PIPELINE_FORM)
         try:
             dec.decode_candidates_dev(mag, cands, counts, m, st_pipe)
             dec.synchronize()
         finally:
-            dec.set_debug_flags(0)
+            dec.set_debug_flags(base_flags)
         h_mag, h_counts = mag.cpu().numpy(), counts.cpu().numpy()
         h_cands = cands.cpu().numpy().view(O.CAND_DTYPE).reshape(m, cap)
         g_stage, g_pipe = st_stage.cpu().numpy(), st_pipe.cpu().numpy()

@@ -41,6 +41,10 @@ def main():
                     help="draw K_LDPC_ITERS per batch from 20, 20, 1, 5, 13, 50 on both sides (the reference fixes 20, rtlsdr_ft8d.h:45, and passes it "
                          "at rtlsdr_ft8d.c:1476; the kernel's iteration loop, its skipped dead last update and the iteration field of the status "
                          "record must follow upstream's bp_decode at any cap)")
+    ap.add_argument("--debug-flags", type=int, default=0,
+                    help="FT8GPU_DBG_* bits for the context: 1 = every BP division through the compiler's IEEE expansion and the reference-domain "
+                         "sums (the complete second instruction stream of the LDPC kernel, which a normal run enters only for the iterations whose "
+                         "guard fails); 4 = the plain pipeline (one launch per stage) whatever the batch size.  Results must not depend on them")
     ap.add_argument("--wide-iters", action="store_true",
                     help="draw K_LDPC_ITERS from 1, 2, 3, 19, 20, 21, 50, 137, 1000 (the accepted range is 1 ... 1000; use small batches: a "
                          "candidate that never converges costs the oracle fifty times the usual at 1000)")
@@ -71,6 +75,8 @@ def main():
     start_all = np.full((B, 1400), fill, np.uint8).view(O.RESULT_DTYPE).reshape(B, 50) if mixed else None
     rng = np.random.default_rng(args.seed)
     dec = ft8.Decoder(device=0, max_frames=B)
+    if args.debug_flags:
+        dec.set_debug_flags(args.debug_flags)
     iq = torch.empty((B, 2, ft8.NSAMPLES), dtype=torch.float32, device="cuda")
     spots = torch.zeros((B, 1400), dtype=torch.uint8, device="cuda")
     nres = torch.zeros((B,), dtype=torch.int32, device="cuda")
@@ -114,7 +120,7 @@ def main():
         mism = [k for k in range(B) if gn[k] != rn[k] or g[k].tobytes() != rdec[k].tobytes()]
         if args.records:
             before = stage_check.differing(stages)
-            stage_check.stage_boundaries_vs_oracle(ft8, O, dec, iq, B, cap, min_score, iters, cores, counters=stages, first_bad=first_bad)
+            stage_check.stage_boundaries_vs_oracle(ft8, O, dec, iq, B, cap, min_score, iters, cores, counters=stages, first_bad=first_bad, base_flags=args.debug_flags)
             if stage_check.differing(stages) != before:
                 print(f"batch {b}: stage boundaries differ: {stages} first {first_bad}", flush=True)
         w = int(sum(1 for k in range(B) for j in range(min(int(gn[k]), 50)) if g[k, j].tobytes() != stale_rec)) if mixed else int(np.minimum(gn, 50).sum())
@@ -123,7 +129,7 @@ def main():
     print(json.dumps({"frames": total, "messages": msgs, "cq_spots_written": written, "mismatching_frames": bad, "seconds": round(time.time() - t0, 1), "seed": args.seed,
                       "batches": args.batches, "traffic": args.traffic, "edges": bool(args.edges), "vary_min_score": bool(args.vary_min_score), "initial_record_byte": fill, "messages_per_frame": round(msgs / max(total, 1), 3),
                       "cq_spots_per_frame": round(written / max(total, 1), 3), "build_id": build_id,
-                      "vary_iters": bool(args.vary_iters), "vary_frames": bool(args.vary_frames), "wide_caps": bool(args.wide_caps), "wide_iters": bool(args.wide_iters), "vary_gain": bool(args.vary_gain), **({"gains_min_max": [min(gains), max(gains)], "batches_scaled": len(gains)} if gains else {}), **({"batch_sizes_min_median_max": [int(min(sizes)), int(np.median(sizes)), int(max(sizes))], "batches_below_512_frames": int(sum(x < 512 for x in sizes))} if sizes else {}), "frames_by_ldpc_iters": {str(k): v for k, v in sorted(iters_hist.items())},
+                      "vary_iters": bool(args.vary_iters), "vary_frames": bool(args.vary_frames), "debug_flags": args.debug_flags, "wide_caps": bool(args.wide_caps), "wide_iters": bool(args.wide_iters), "vary_gain": bool(args.vary_gain), **({"gains_min_max": [min(gains), max(gains)], "batches_scaled": len(gains)} if gains else {}), **({"batch_sizes_min_median_max": [int(min(sizes)), int(np.median(sizes)), int(max(sizes))], "batches_below_512_frames": int(sum(x < 512 for x in sizes))} if sizes else {}), "frames_by_ldpc_iters": {str(k): v for k, v in sorted(iters_hist.items())},
                       **({"stages": stages, "stage_differences_total": stage_check.differing(stages), "first_differences": first_bad} if args.records else {})}))
     return 1 if bad or (args.records and stage_check.differing(stages)) else 0
 
