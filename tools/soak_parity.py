@@ -33,6 +33,9 @@ def main():
                          "quantiser (rtlsdr_ft8d.c:1413-1433) then works all over its range and into both clamps -- 0 below -120 dB, 255 above "
                          "+7.5 dB -- where the device's threshold table stands in for log10f; partly or wholly saturated waterfalls also give "
                          "candidates whose LLRs are all zero (variance 0: the scale factor is inf, the LLRs NaN, as in the reference)")
+    ap.add_argument("--gain-decades", type=float, nargs=2, default=(-4.0, 2.5), metavar=("LO", "HI"),
+                    help="exponent range of --vary-gain (default -4 2.5; -18 17 reaches denormal products at one end and |X|^2 = +inf at the other: "
+                         "the quantiser's fence for +inf is 255 on both sides, DESIGN.md section 2)")
     ap.add_argument("--wide-caps", action="store_true",
                     help="draw K_MAX_CANDIDATES per batch from the whole accepted range instead of 60 ... 480: 1, 2, 7, 33, 120, 481, 777, 1024 "
                          "(FT8GPU_ABS_MAX_CANDIDATES; the reference fixes 120, rtlsdr_ft8d.h:44): a heap of one entry, caps off the 4-candidate "
@@ -105,7 +108,7 @@ def main():
         dec.synth_frames(sig, B, nsig, 1.0, 777 + b + (args.seed - 123) * 100_003, iq)
         gain = 1.0
         if args.vary_gain and rng.integers(0, 3) != 0:
-            gain = float(10.0 ** rng.uniform(-4.0, 2.5))
+            gain = float(10.0 ** rng.uniform(args.gain_decades[0], args.gain_decades[1]))
             dec.synchronize()                            # the synthesis runs on the decoder's stream, the scaling on torch's
             iq.mul_(gain)
             gains.append(gain)
