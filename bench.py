@@ -171,7 +171,7 @@ METRIC = "15 s FT8 frames decoded/s"
 WATCHDOG_CODE = r"""
 import json, os, select, signal, sys, time
 rank, world, ppid, metric = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
-phase, deadline, since, buf, history = "start", None, time.time(), b"", []
+phase, deadline, since, buf, history, result = "start", None, time.time(), b"", [], None
 while True:
     r, _, _ = select.select([0], [], [], None if deadline is None else max(0.0, deadline - time.time()))
     if r:
@@ -181,9 +181,13 @@ while True:
         buf += chunk
         while b"\n" in buf:
             ln, buf = buf.split(b"\n", 1)
-            w = ln.decode().split(" ")
+            w = ln.decode().split(" ", 1)
             if w[0] == "done":
                 sys.exit(0)
+            if w[0] == "result":                     # the rank's measured line so far: printed in its place should it hang afterwards
+                result = w[1]
+                continue
+            w = ln.decode().split(" ")
             history.append([phase, round(time.time() - since, 2)])
             phase, since = w[1], time.time()
             deadline = since + float(w[2])
@@ -192,8 +196,14 @@ while True:
         msg = {"metric": metric, "value": None, "unit": "frames/s", "n_gpus": world, "failed": True, "rank": rank, "phase": phase,
                "error": "rank %d of %d hung in phase '%s' for %.0f s (limit %.0f s); killed by its watchdog" % (rank, world, phase, waited, deadline - since),
                "phases_completed": history[1:], "pid": ppid}
+        note = msg["error"]
+        if result is not None:
+            # the timed region was over and reduced when the rank hung: the measurement stands; say what did not complete
+            line = json.loads(result)
+            line.update({"completed": False, "hung_after_timing_in_phase": phase, "watchdog": note})
+            msg = line
         sys.stdout.write(json.dumps(msg) + "\n"); sys.stdout.flush()
-        sys.stderr.write("bench.py watchdog: " + msg["error"] + "\n"); sys.stderr.flush()
+        sys.stderr.write("bench.py watchdog: " + note + "\n"); sys.stderr.flush()
         try:
             os.kill(ppid, signal.SIGKILL)
         except OSError:
@@ -214,6 +224,15 @@ class RankWatchdog:
         if self.p:
             try:
                 self.p.stdin.write(f"phase {name} {timeout or self.default_timeout}\n".encode())
+                self.p.stdin.flush()
+            except OSError:
+                pass
+
+    def result(self, line):
+        """deposit the rank's measured line: should the rank hang in a later phase, the watchdog prints it (marked incomplete)"""
+        if self.p:
+            try:
+                self.p.stdin.write(b"result " + json.dumps(line).encode() + b"\n")
                 self.p.stdin.flush()
             except OSError:
                 pass
@@ -590,7 +609,12 @@ def main():
         """a rank that fails after start-up leaves ONE diagnosable JSON line and a non-zero status; no clean shutdown of a broken group"""
         import traceback
         traceback.print_exc()
-        print(failure_line(out, rank, world, wd.current, exc, ctl["store"], extra), flush=True)
+        if rank == 0 and out.get("value") is not None:
+            # the timed region was complete and reduced: the measurement stands, the error is reported beside it
+            out.update({"completed": False, "error_after_timing": f"{type(exc).__name__}: {exc}"[:1000], "error_phase": wd.current})
+            print(json.dumps(out), flush=True)
+        else:
+            print(failure_line(out, rank, world, wd.current, exc, ctl["store"], extra), flush=True)
         wd.done()
         sys.stdout.flush()
         sys.stderr.flush()
@@ -862,6 +886,8 @@ def main():
 
         out["value"] = round(total * args.steps / elapsed, 1)
         out["ms_per_step"] = round(1e3 * elapsed / args.steps, 3)
+        if rank == 0:
+            wd.result(out)               # from here on a hang or an error costs diagnostics, not the measurement (see RankWatchdog.result, die)
         out["step_ms"] = {"min": round(min(per_step), 4), "median": round(float(np.median(per_step)), 4), "max": round(max(per_step), 4),
                           "slowest_step_index": int(np.argmax(per_step)),
                           "note": "hipEvent time between consecutive steps' last kernels on rank 0's stream"}
@@ -879,22 +905,33 @@ def main():
         rec = spots.view(B, ft8.MAX_MESSAGES, 28)
         used = torch.arange(ft8.MAX_MESSAGES, device=dev)[None, :] < nres[:, None]
         out["config"]["cq_spots_per_frame"] = round(float(((rec != 0).any(dim=2) & used).sum().item()) / B, 2)
+        if rank == 0:
+            wd.result(out)
         if exchange and world > 1:
-            # the gathered list of the last step must hold every rank's records in global frame order
-            gs, gc = exch.gathered(state["k"] - 1)
-            mine = bool(torch.equal(gs[lo:hi], spots)) and bool(torch.equal(gc[lo:hi], nres))
-            flag = torch.tensor([1 if mine else 0], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            out["gathered_list_holds_every_ranks_shard"] = bool(flag.item())
-            out["config"]["gathered_messages_per_frame"] = round(float(gc.float().mean().item()), 2)
+            # the gathered list of the last step must hold every rank's records in global frame order (this block first runs on the
+            # first node with two GPUs: whatever it does, the measurement above stands)
+            try:
+                gs, gc = exch.gathered(state["k"] - 1)
+                mine = bool(torch.equal(gs[lo:hi], spots)) and bool(torch.equal(gc[lo:hi], nres))
+                flag = torch.tensor([1 if mine else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                out["gathered_list_holds_every_ranks_shard"] = bool(flag.item())
+                out["config"]["gathered_messages_per_frame"] = round(float(gc.float().mean().item()), 2)
+            except Exception as e:               # noqa: BLE001
+                out["gathered_list_check_error"] = f"{type(e).__name__}: {e}"[:500]
+            if rank == 0:
+                wd.result(out)
         if args.sustain_seconds > 0:
             # a side figure, never the headline: the same loop for S seconds (step count fixed from the all-reduced step time,
             # so every rank runs the same number of collectives)
             n_sus = max(64, int(np.ceil(args.sustain_seconds * 1e3 / (1e3 * elapsed / args.steps))))
             enter("sustained", args.dist_timeout + 3.0 * args.sustain_seconds + 60.0)
-            sus = run_sustained(args, torch, dist, step, fence, stream, local_rank, n_sus, B, world, use_dist, dev, 1e3 * elapsed / args.steps)
-            if rank == 0:
-                out["sustained"] = sus
+            try:
+                sus = run_sustained(args, torch, dist, step, fence, stream, local_rank, n_sus, B, world, use_dist, dev, 1e3 * elapsed / args.steps)
+                if rank == 0:
+                    out["sustained"] = sus
+            except Exception as e:               # noqa: BLE001 -- a side figure: its failure must not take the headline with it
+                out["sustained_error"] = f"{type(e).__name__}: {e}"[:500]
     except Exception as e:                       # noqa: BLE001
         if not use_dist:
             raise
