@@ -658,3 +658,16 @@ def test_device_outputs_stay_inside_their_buffers():
     torch.cuda.synchronize()
     assert int(nres.sum().item()) > 2 * n and int(counts.sum().item()) > 5 * n and int(glen.sum().item()) > 100 * n     # the entries really ran
     assert ar.guards_intact(), "a device-pointer entry wrote outside the buffer it was given"
+
+
+def test_bench_measurement_survives_a_hang_after_the_timed_region():
+    """a rank that hangs AFTER the timed steps were reduced (here: test hook in the `report` phase; on a real node: a diagnostic
+    collective or the shutdown barrier) must not take the measurement with it: rank 0 deposits its line with the watchdog as soon
+    as `value` exists, and the watchdog prints that line -- marked incomplete, with the phase -- when it kills the rank"""
+    rc, lines, err = _bench_cmd("--force-dist", "--frames", "512", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-host-legs",
+                                "--dist-timeout", "150", "--test-hang", "0:report:5")
+    assert rc != 0
+    assert len(lines) == 1, (lines, err[-1500:])
+    ln = lines[0]
+    assert ln["value"] > 100000 and ln["completed"] is False and ln["hung_after_timing_in_phase"] == "report" and "hung in phase 'report'" in ln["watchdog"]
+    assert ln["n_gpus"] == 1 and ln["steps"] == 3 and ln["ms_per_step"] > 0 and "step_ms" in ln
