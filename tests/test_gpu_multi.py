@@ -503,7 +503,7 @@ def test_bench_one_rank_rccl_leg_first_contact_fields_and_sustained_run():
     watchdog's phases, the decode-only rate measured before RCCL exists, the first all-reduce, the c10d-store exchange of rank
     identities (PCI address, RCCL version, visible devices), and a short --sustain-seconds run after the timed steps."""
     rc, lines, err = _bench_cmd("--force-dist", "--frames", "1024", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-host-legs",
-                                "--sustain-seconds", "1.5")
+                                "--sustain-seconds", "1.5", "--prewarm-seconds", "0.2")
     assert rc == 0 and len(lines) == 1, err[-3000:]
     ln = lines[0]
     assert ln["rccl_ranks"] == 1 and ln["backend"] == "nccl" and ln["value"] > 100000
@@ -523,7 +523,7 @@ def test_bench_rank_hanging_at_its_first_collective_is_killed_and_named():
     import time
     t0 = time.time()
     rc, lines, err = _bench_cmd("--force-dist", "--frames", "512", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-host-legs",
-                                "--dist-timeout", "150", "--test-hang", "0:first_collective:6")     # generous limit for the real phases (cold RCCL load)
+                                "--dist-timeout", "150", "--prewarm-seconds", "0.2", "--test-hang", "0:first_collective:3")     # generous limit for the real phases (cold RCCL load)
     assert rc != 0 and time.time() - t0 < 180
     failed = [ln for ln in lines if ln.get("failed")]
     assert failed and failed[0]["rank"] == 0 and failed[0]["phase"] == "first_collective", (lines, err[-2000:])
@@ -665,7 +665,7 @@ def test_bench_measurement_survives_a_hang_after_the_timed_region():
     collective or the shutdown barrier) must not take the measurement with it: rank 0 deposits its line with the watchdog as soon
     as `value` exists, and the watchdog prints that line -- marked incomplete, with the phase -- when it kills the rank"""
     rc, lines, err = _bench_cmd("--force-dist", "--frames", "512", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-host-legs",
-                                "--dist-timeout", "150", "--test-hang", "0:report:5")
+                                "--dist-timeout", "150", "--prewarm-seconds", "0.2", "--test-hang", "0:report:3")
     assert rc != 0
     assert len(lines) == 1, (lines, err[-1500:])
     ln = lines[0]
